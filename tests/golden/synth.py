@@ -1,0 +1,104 @@
+"""Bit-reproducible synthetic inputs shared by the golden-vector generator and the tests.
+
+Everything is derived from a 32-bit multiplicative hash of the element index, so the same
+tensors are rebuilt exactly on any machine and only OUTPUTS need to be stored as fixtures.
+"""
+
+import numpy as np
+import torch
+
+
+def lcg(shape, seed, scale=1.0, dtype=np.float32):
+    """Uniform values in [-scale/2, scale/2) from an integer hash of (seed, index); exact in float64."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64)
+    x = (idx + np.uint64(seed) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    x = (x * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    u = x.astype(np.float64) / 4294967296.0 - 0.5
+    return (u * scale).astype(dtype).reshape(shape)
+
+
+def lcg_t(shape, seed, scale=1.0, dtype=torch.float32):
+    return torch.from_numpy(lcg(tuple(shape), seed, scale, np.float64)).to(dtype)
+
+
+def gaussianish(shape, seed, dtype=torch.float32):
+    """Sum of 4 uniforms, rescaled to unit variance: a smooth bell-shaped stand-in for N(0,1)."""
+    s = sum(lcg(tuple(shape), seed * 4 + j, 1.0, np.float64) for j in range(4))
+    return torch.from_numpy(s * np.sqrt(3.0)).to(dtype)
+
+
+def make_params(names_shapes, seed):
+    """Weights ~ U(-1,1)/sqrt(fan_in), LayerNorm gains near 1, small biases, in the given order."""
+    out = {}
+    for j, (name, shape) in enumerate(names_shapes):
+        s = seed * 1000 + j
+        if len(shape) == 2:
+            out[name] = lcg_t(shape, s, 2.0 / np.sqrt(shape[1]))
+        elif name.endswith('.weight'):  # LayerNorm gain
+            out[name] = 1.0 + lcg_t(shape, s, 0.2)
+        else:
+            out[name] = lcg_t(shape, s, 0.1)
+    return out
+
+
+def actor_critic_shapes(obs_dim, act_dim, units, norm=True, act=True, fixed_sigma=False):
+    """(name, shape) list in the order of the reference model's parameters()."""
+    stride = 1 + int(norm) + int(act)
+    res = []
+    if fixed_sigma:
+        res.append(('sigma', (act_dim,)))
+    for tower in ('actor_mlp', 'value_mlp'):
+        in_f = obs_dim
+        for i, out_f in enumerate(units):
+            b = i * stride
+            res += [(f'{tower}.mlp.{b}.weight', (out_f, in_f)), (f'{tower}.mlp.{b}.bias', (out_f,))]
+            if norm:
+                res += [(f'{tower}.mlp.{b + 1}.weight', (out_f,)), (f'{tower}.mlp.{b + 1}.bias', (out_f,))]
+            in_f = out_f
+    res += [('value.weight', (1, units[-1])), ('value.bias', (1,))]
+    res += [('mu.weight', (act_dim, units[-1])), ('mu.bias', (act_dim,))]
+    if not fixed_sigma:
+        res += [('sigma.weight', (act_dim, units[-1])), ('sigma.bias', (act_dim,))]
+    return res
+
+
+class Space:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class GoldenEnv:
+    """Deterministic vector env: obs/reward are hash-derived and lightly coupled to the clamped actions."""
+
+    def __init__(self, num_envs, obs_dim, act_dim, episode_length=5, seed=7, device='cpu'):
+        self.num_envs, self.obs_dim, self.act_dim = num_envs, obs_dim, act_dim
+        self.episode_length, self.seed, self.device = episode_length, seed, device
+        self.observation_space = Space((obs_dim,))
+        self.action_space = Space((act_dim,))
+        self.t = 0
+        self.counters = torch.arange(num_envs) % episode_length
+
+    def _obs(self):
+        return gaussianish((self.num_envs, self.obs_dim), self.seed * 100003 + self.t).to(self.device)
+
+    def reset(self):
+        self.t = 0
+        self.counters = torch.arange(self.num_envs) % self.episode_length
+        return self._obs()
+
+    def step(self, actions):
+        self.t += 1
+        a = actions.detach().to('cpu')
+        obs = self._obs().to('cpu')
+        obs[:, : self.act_dim] += 0.5 * a
+        rew = gaussianish((self.num_envs,), self.seed * 7919 + self.t) + 0.01 * a.sum(1)
+        self.counters = self.counters + 1
+        done = self.counters >= self.episode_length
+        self.counters = torch.where(done, torch.zeros_like(self.counters), self.counters)
+        return obs.to(self.device), rew.to(self.device), done.to(self.device), {'time_outs': done.to(self.device)}
