@@ -1,0 +1,19 @@
+# Builds the gfx950 shared library (C ABI) in-tree.  `make` here, on CPU: hipcc cross-compiles.
+HIPCC ?= /opt/rocm/bin/hipcc
+HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-value
+SRC = mineral_amd/csrc/ppo_capi.hip
+HDR = mineral_amd/csrc/gemm.hip.h include/mineral_ppo.h
+LIB = mineral_amd/libmineral_ppo.so
+
+all: $(LIB)
+
+$(LIB): $(SRC) $(HDR)
+	$(HIPCC) $(HIPFLAGS) $(SRC) -o $@
+
+# per-kernel register / LDS / spill table
+resources: $(SRC) $(HDR)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage $(SRC) -o /tmp/_mrl_res.so 2>&1 | python3 tools/resource_table.py
+
+clean:
+	rm -f $(LIB)
+.PHONY: all resources clean

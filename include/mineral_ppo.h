@@ -1,0 +1,166 @@
+/* mineral_ppo.h — C ABI of the MI355X (gfx950) PPO actor-learner hot path.
+ *
+ * The reference (jacr13/mineral) is pure Python on torch and has no FFI of its own; its plugin boundary is the
+ * Python classes named below.  Each entry point here is what a binding for that reference call would use.
+ * Citations are `mineral/<path>:<lines>` in the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`; fp32 unless typed otherwise
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued, nothing syncs
+ *   - every function returns 0 on success or a negative MRL_E* code; mrl_last_error() gives the message of the
+ *     calling thread's last failure.  Nothing here allocates device memory: callers pass workspaces sized by
+ *     mrl_workspace_bytes().
+ *   - layouts: the rollout buffer is ENV-MAJOR for per-sample vectors, so the flat sample index of
+ *     (env n, step t) is n*T + t — exactly the index map produced by transpose(0,1)+reshape in
+ *     mineral/agents/ppo/experience.py:7-14 — and minibatch i is the contiguous row range [i*mb, (i+1)*mb)
+ *     (experience.py:61-64).  Per-step scalars are staged TIME-MAJOR ([T][N]) during collection and converted by
+ *     mrl_gae_finish.
+ */
+#ifndef MINERAL_PPO_H
+#define MINERAL_PPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRL_OK 0
+#define MRL_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MRL_ENOSPC (-2)   /* workspace too small */
+#define MRL_EHIP (-3)     /* a HIP call or launch failed */
+
+#define MRL_MAX_LAYERS 4
+#define MRL_DIST_NORMAL 0
+#define MRL_DIST_DREAMERV3_NORMAL 1
+#define MRL_NMETRIC 12
+
+/* ActorCritic description: two towers of [Linear -> LayerNorm -> SiLU] x n_layers, heads mu/sigma (actor) and
+ * value (critic).  mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.
+ * Limits of this build: units multiples of 32 and <= 512, obs_dim multiple of 4, act_dim <= 16,
+ * norm_type LayerNorm, act_type SiLU, fixed_sigma False. */
+typedef struct mrl_net {
+  int32_t obs_dim;
+  int32_t act_dim;
+  int32_t n_layers;
+  int32_t units[MRL_MAX_LAYERS];
+  int32_t dist_type;
+  float minstd, maxstd;
+  float ln_eps;
+} mrl_net;
+
+/* RunningMeanStd state, mineral/common/normalizers.py:19-42 (fp64 buffers as built at ppo.py:30). */
+typedef struct mrl_rms {
+  double* mean;   /* [size] */
+  double* var;    /* [size] */
+  double* count;  /* [1]    */
+  int32_t size;
+  float eps;
+  float clamp_lo, clamp_hi;
+} mrl_rms;
+
+/* Device-resident rollout storage, mineral/agents/ppo/experience.py:18-56. */
+typedef struct mrl_rollout {
+  int64_t num_envs;      /* N */
+  int32_t horizon;       /* T */
+  float* obs;            /* [N][T][obs_dim] */
+  float* actions;        /* [N][T][act_dim]  (unclamped samples) */
+  float* mu;             /* [N][T][act_dim] */
+  float* sigma;          /* [N][T][act_dim] */
+  float* neglogp_tn;     /* [T][N] */
+  float* values_tn;      /* [T][N]  un-normalised value predictions */
+  float* rewards_tn;     /* [T][N]  shaped rewards */
+  uint8_t* dones_tn;     /* [T][N] */
+  /* flat per-sample scalars (index n*T+t), written by mrl_gae_finish */
+  float* values;         /* value_preds, normalised if normalize_value */
+  float* returns;
+  float* advantages;
+  float* neglogp;
+} mrl_rollout;
+
+/* PPO loss hyper-parameters, mineral/agents/ppo/ppo.py:63-76. */
+typedef struct mrl_ppo_hp {
+  float e_clip;
+  float critic_coef;
+  float entropy_coef;
+  float bounds_loss_coef;
+  int32_t bounds_type;       /* 0 'bound', 1 'reg' (ppo.py:479-489) */
+  int32_t clip_value_loss;
+} mrl_ppo_hp;
+
+const char* mrl_last_error(void);
+int mrl_version(void);
+
+/* Number of fp32 elements of the flat parameter vector and the offset of every tensor in it.
+ * Order: per tower (actor, critic) per layer W[u][in], b[u], ln_gamma[u], ln_beta[u]; then the actor head
+ * W[2A][U] (rows 0..A-1 = mu.weight, A..2A-1 = sigma.weight), b[2A]; then value.weight[1][U], value.bias[1].
+ * Every offset is a multiple of 4.  offsets_host has room for 2*4*MRL_MAX_LAYERS + 4 entries. */
+int64_t mrl_param_count(const mrl_net* net);
+int mrl_param_offsets(const mrl_net* net, int64_t* offsets_host, int32_t* n_tensors_host);
+
+/* Bytes of scratch the calls below need for `rows` simultaneous samples (minibatch rows or envs). */
+int64_t mrl_workspace_bytes(const mrl_net* net, int64_t rows);
+
+/* PPO.model_act + ExperienceBuffer.update_data for one env step (ppo.py:125-131,144-148; models.py:110-126):
+ * normalise obs with obs_rms (no update), run both towers, sample a = mu + sigma*noise, neglogp, un-normalise the
+ * value with value_rms, and write row t of the buffer (obs, actions, mu, sigma, neglogp_tn, values_tn).
+ * actions_clamped [N][A] receives clamp(a,-1,1) for env.step (ppo.py:150).  With t == horizon only the values are
+ * computed and written to last_values [N] (the bootstrap forward at ppo.py:169-170).
+ * obs_rms / value_rms may be NULL (normalize_input / normalize_value off). */
+int mrl_policy_act(const mrl_net* net, const float* params, const mrl_rms* obs_rms, const mrl_rms* value_rms,
+                   const float* obs, const float* noise, int32_t t, const mrl_rollout* buf, float* actions_clamped,
+                   float* last_values, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Reward shaping + time-out bootstrap + done flags of one step (ppo.py:153-163, reward_shaper.py:10-15):
+ * rewards_tn[t] = r*scale (+ gamma*values_tn[t]*time_outs), dones_tn[t] = dones.  time_outs may be NULL. */
+int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,
+                      const uint8_t* time_outs, float reward_scale, float gamma, void* stream);
+
+/* ExperienceBuffer.compute_return + prepare_training + the value-normalisation stage
+ * (experience.py:96-121, ppo.py:172-183): GAE(lambda) reverse scan, env-major flattening of the per-sample
+ * scalars, whole-batch advantage normalisation (unbiased std, +1e-8), then value_rms.update(values) /
+ * normalize / update(returns) / normalize.  value_rms may be NULL (normalize_value off).
+ * stats_out (optional, 8 floats): adv mean, adv std, value mean/std after 1st update, after 2nd update. */
+int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, float gamma, float tau,
+                   const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
+/* Batch moments of x [rows][cols] per group of `group_rows` consecutive rows: mean (fp32) and variance with the
+ * given correction (fp32), as x.mean(0) / x.var(0, correction) in RunningMeanStd.update
+ * (normalizers.py:57-63).  Outputs are [rows/group_rows][cols]. */
+int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int64_t group_rows, int32_t correction,
+                      float* mean_out, float* var_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* RunningMeanStd._update_from_moments (normalizers.py:44-55) in the state's fp64, from fp32 batch moments;
+ * also emits mean.float() and sqrt(var.float()+eps) [size each] for the normalising kernels. */
+int mrl_rms_merge(const mrl_rms* rms, const float* batch_mean, const float* batch_var, double batch_count,
+                  float* mean_f32_out, float* std_f32_out, void* stream);
+
+/* RunningMeanStd.normalize / unnormalize (normalizers.py:65-78), element-wise, for callers outside the fused
+ * path and for tests. */
+int mrl_rms_normalize(const mrl_rms* rms, const float* x, float* y, int64_t rows, int32_t unnormalize, void* stream);
+
+/* One minibatch of PPO.train_epoch up to (not including) the optimizer step (ppo.py:254-292,302-313):
+ * forward of both towers on rows [row0, row0+mb) of the buffer, actor/critic/bounds/entropy losses, backward,
+ * flat gradient (layout of mrl_param_offsets), policy_kl against the stored mu/sigma, and the write-back of the
+ * new mu/sigma.  obs_mean/obs_std are the fp32 normaliser vectors of mrl_rms_merge (NULL = no input norm).
+ * metrics_out: MRL_NMETRIC doubles = a_loss, entropy, b_loss, kl, clip_frac, c_loss (all means over the
+ * minibatch), explained_var, total loss, then 4 reserved. */
+int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
+                 int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
+                 float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* clip_grad_norm_ + torch.optim.Adam/AdamW step on the flat vectors (ppo.py:294-300):
+ * g = grads*grad_scale; norm = ||g||; g *= min(max_norm/(norm+1e-6), 1) if max_norm > 0; then Adam (adamw=0:
+ * L2 weight decay folded into g) or AdamW (decoupled decay).  `step` is the 1-based step count.
+ * gnorm_out (optional, 1 float) receives the pre-clip norm.  scratch: >= 4096 bytes. */
+int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
+                  float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""ctypes binding of `libmineral_ppo.so` (the C ABI declared in include/mineral_ppo.h).
+
+The library is the product: there is no Python/torch fallback.  If it has not been built (`make` at the repo
+root) importing a function from here raises immediately.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmineral_ppo.so')
+
+MAX_LAYERS = 4
+NMETRIC = 12
+DIST_TYPES = {'normal': 0, 'dreamerv3_normal': 1}
+METRIC_NAMES = ('loss/actor', 'loss/entropy', 'loss/bounds', 'kl', 'clip_frac', 'loss/critic', 'explained_var', 'loss/total')
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class Net(C.Structure):
+    _fields_ = [('obs_dim', C.c_int32), ('act_dim', C.c_int32), ('n_layers', C.c_int32), ('units', C.c_int32 * MAX_LAYERS),
+                ('dist_type', C.c_int32), ('minstd', C.c_float), ('maxstd', C.c_float), ('ln_eps', C.c_float)]
+
+
+class Rms(C.Structure):
+    _fields_ = [('mean', C.c_void_p), ('var', C.c_void_p), ('count', C.c_void_p), ('size', C.c_int32), ('eps', C.c_float),
+                ('clamp_lo', C.c_float), ('clamp_hi', C.c_float)]
+
+
+class Rollout(C.Structure):
+    _fields_ = [('num_envs', C.c_int64), ('horizon', C.c_int32), ('obs', C.c_void_p), ('actions', C.c_void_p),
+                ('mu', C.c_void_p), ('sigma', C.c_void_p), ('neglogp_tn', C.c_void_p), ('values_tn', C.c_void_p),
+                ('rewards_tn', C.c_void_p), ('dones_tn', C.c_void_p), ('values', C.c_void_p), ('returns', C.c_void_p),
+                ('advantages', C.c_void_p), ('neglogp', C.c_void_p)]
+
+
+class PpoHp(C.Structure):
+    _fields_ = [('e_clip', C.c_float), ('critic_coef', C.c_float), ('entropy_coef', C.c_float), ('bounds_loss_coef', C.c_float),
+                ('bounds_type', C.c_int32), ('clip_value_loss', C.c_int32)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    'mrl_last_error': (C.c_char_p, []),
+    'mrl_version': (C.c_int, []),
+    'mrl_param_count': (C.c_int64, [C.POINTER(Net)]),
+    'mrl_param_offsets': (C.c_int, [C.POINTER(Net), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'mrl_workspace_bytes': (C.c_int64, [C.POINTER(Net), C.c_int64]),
+    'mrl_policy_act': (C.c_int, [C.POINTER(Net), _P, C.POINTER(Rms), C.POINTER(Rms), _P, _P, C.c_int32, C.POINTER(Rollout), _P, _P,
+                                 _P, C.c_int64, _P]),
+    'mrl_rollout_write': (C.c_int, [C.POINTER(Rollout), C.c_int32, _P, _P, _P, C.c_float, C.c_float, _P]),
+    'mrl_gae_finish': (C.c_int, [C.POINTER(Rollout), _P, C.c_float, C.c_float, C.POINTER(Rms), _P, _P, C.c_int64, _P]),
+    'mrl_batch_moments': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    'mrl_rms_merge': (C.c_int, [C.POINTER(Rms), _P, _P, C.c_double, _P, _P, _P]),
+    'mrl_rms_normalize': (C.c_int, [C.POINTER(Rms), _P, _P, C.c_int64, C.c_int32, _P]),
+    'mrl_ppo_grad': (C.c_int, [C.POINTER(Net), _P, C.POINTER(PpoHp), C.POINTER(Rollout), C.c_int64, C.c_int64, _P, _P, C.c_float,
+                               C.c_float, _P, _P, _P, C.c_int64, _P]),
+    'mrl_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise HipLibraryError (never fall back) if it is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(f'{LIB_PATH} not found: build it with `make` at the repository root '
+                                  '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise HipLibraryError(f'{LIB_PATH} does not export {name}') from e
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().mrl_last_error().decode('utf-8', 'replace')
+        if status == -1:
+            raise ValueError(f'{what}: {msg}')
+        raise HipLibraryError(f'{what} failed ({status}): {msg}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=1e-5):
+    if len(units) > MAX_LAYERS:
+        raise ValueError(f'at most {MAX_LAYERS} hidden layers are supported, got {len(units)}')
+    if dist_type not in DIST_TYPES:
+        raise NotImplementedError(dist_type)
+    n = Net()
+    n.obs_dim, n.act_dim, n.n_layers = obs_dim, act_dim, len(units)
+    for i, u in enumerate(units):
+        n.units[i] = int(u)
+    n.dist_type, n.minstd, n.maxstd, n.ln_eps = DIST_TYPES[dist_type], minstd, maxstd, ln_eps
+    return n

@@ -1,0 +1,151 @@
+"""ActorCritic parameter container for the HIP towers (interface of mineral/agents/ppo/models.py:29-151).
+
+All parameters live in ONE flat fp32 device vector whose layout is fixed by the library
+(`mrl_param_offsets`); the tensors exposed under the reference's `state_dict` names are views into it, so a
+checkpoint written by either implementation loads into the other.
+"""
+
+import math
+from collections import OrderedDict
+
+import torch
+
+from ... import _hip
+
+
+class ActorCritic:
+    def __init__(self, obs_space, action_dim, mlp_kwargs=None, critic_mlp_kwargs=None, separate_value_mlp=True,
+                 fixed_sigma=True, actor_dist_kwargs=None, weight_init='orthogonal', encoder=None, encoder_kwargs=None,
+                 device='cuda'):
+        mlp_kwargs = dict(mlp_kwargs or dict(units=[512, 256, 128], act_type='ELU'))
+        dist = dict(actor_dist_kwargs or dict(dist_type='normal'))
+        unsupported = []
+        if 'obs' not in obs_space:
+            unsupported.append('dict observations (MultiEncoder)')
+        if not separate_value_mlp:
+            unsupported.append('separate_value_mlp=False')
+        if critic_mlp_kwargs is not None:
+            unsupported.append('critic_mlp_kwargs')
+        if fixed_sigma:
+            unsupported.append('fixed_sigma=True')
+        if mlp_kwargs.get('norm_type', None) != 'LayerNorm':
+            unsupported.append(f"norm_type={mlp_kwargs.get('norm_type', None)}")
+        if mlp_kwargs.get('act_type', 'ReLU') != 'SiLU':
+            unsupported.append(f"act_type={mlp_kwargs.get('act_type', 'ReLU')}")
+        if mlp_kwargs.get('dropout', None) is not None or mlp_kwargs.get('plain_last', False) or mlp_kwargs.get('out_dim', None):
+            unsupported.append('dropout / plain_last / out_dim')
+        if dist.get('dist_type', 'normal') not in _hip.DIST_TYPES:
+            unsupported.append(f"dist_type={dist.get('dist_type')}")
+        if dist.get('minlogstd', None) is not None or dist.get('maxlogstd', None) is not None:
+            unsupported.append('minlogstd / maxlogstd')
+        if weight_init != 'orthogonal':
+            unsupported.append(f'weight_init={weight_init}')
+        if unsupported:
+            raise NotImplementedError('the MI355X PPO kernels cover LayerNorm+SiLU towers with a state-dependent sigma; '
+                                      'unsupported here: ' + ', '.join(unsupported))
+        self.obs_space, self.action_dim = obs_space, int(action_dim)
+        self.obs_dim = int(obs_space['obs'][0])
+        self.units = [int(u) for u in mlp_kwargs.get('units', [512, 256, 128])]
+        self.ln_eps = float(mlp_kwargs.get('norm_kwargs', {}).get('eps', 1e-5))
+        self.dist_type = dist.get('dist_type', 'normal')
+        self.minstd, self.maxstd = float(dist.get('minstd', 1.0)), float(dist.get('maxstd', 1.0))
+        self.fixed_sigma, self.separate_value_mlp = False, True
+        self.device = torch.device(device)
+        self.net = _hip.make_net(self.obs_dim, self.action_dim, self.units, self.dist_type, self.minstd, self.maxstd, self.ln_eps)
+        L = _hip.lib()
+        count = L.mrl_param_count(self.net)
+        if count < 0:
+            _hip.check(int(count), 'mrl_param_count')
+        self.param_count = int(count)
+        self.flat = torch.zeros(self.param_count, dtype=torch.float32, device=self.device)
+        self._views = self._make_views(self.flat)
+        self.training = True
+        self.reset_parameters()
+
+    # ---- flat <-> named views ----------------------------------------------------------------------------------
+    def _offsets(self):
+        import ctypes as C
+        offs = (C.c_int64 * (2 * 4 * _hip.MAX_LAYERS + 4))()
+        n = C.c_int32(0)
+        _hip.check(_hip.lib().mrl_param_offsets(self.net, offs, C.byref(n)), 'mrl_param_offsets')
+        return list(offs[: n.value])
+
+    def _make_views(self, flat):
+        """Views of `flat` under the reference's parameter names, in the order of its model.parameters()."""
+        offs = self._offsets()
+        A, U = self.action_dim, self.units[-1]
+        v = OrderedDict()
+        k = 0
+        for tower in ('actor_mlp', 'value_mlp'):
+            in_f = self.obs_dim
+            for i, u in enumerate(self.units):
+                b = 3 * i
+                v[f'{tower}.mlp.{b}.weight'] = flat[offs[k]: offs[k] + u * in_f].view(u, in_f)
+                v[f'{tower}.mlp.{b}.bias'] = flat[offs[k + 1]: offs[k + 1] + u]
+                v[f'{tower}.mlp.{b + 1}.weight'] = flat[offs[k + 2]: offs[k + 2] + u]
+                v[f'{tower}.mlp.{b + 1}.bias'] = flat[offs[k + 3]: offs[k + 3] + u]
+                k += 4
+                in_f = u
+        wh, bh, wv, bv = offs[k: k + 4]
+        v['value.weight'] = flat[wv: wv + U].view(1, U)
+        v['value.bias'] = flat[bv: bv + 1]
+        v['mu.weight'] = flat[wh: wh + A * U].view(A, U)
+        v['mu.bias'] = flat[bh: bh + A]
+        v['sigma.weight'] = flat[wh + A * U: wh + 2 * A * U].view(A, U)
+        v['sigma.bias'] = flat[bh + A: bh + 2 * A]
+        return v
+
+    def views_of(self, flat):
+        """Named views into another flat vector of the same layout (gradients, Adam moments)."""
+        return self._make_views(flat)
+
+    def named_parameters(self):
+        return self._views.items()
+
+    def parameters(self):
+        return self._views.values()
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self._views.items())
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._views if k not in sd]
+        extra = [k for k in sd if k not in self._views]
+        if strict and (missing or extra):
+            raise RuntimeError(f'state_dict mismatch: missing {missing}, unexpected {extra}')
+        with torch.no_grad():
+            for k, v in self._views.items():
+                if k in sd:
+                    v.copy_(sd[k].to(self.device, torch.float32))
+
+    # ---- init (mineral/agents/ppo/models.py:8-17,75-91) ------------------------------------------------------------
+    def reset_parameters(self):
+        with torch.no_grad():
+            for name, v in self._views.items():
+                if name.endswith('.weight') and v.dim() == 2:
+                    gain = math.sqrt(2.0)
+                    if name == 'value.weight':
+                        gain = 1.0
+                    elif name in ('mu.weight', 'sigma.weight'):
+                        gain = 0.01
+                    w = torch.empty(v.shape, dtype=torch.float32)
+                    torch.nn.init.orthogonal_(w, gain=gain)
+                    v.copy_(w)
+                elif name.endswith('.weight'):   # LayerNorm gain
+                    v.fill_(1.0)
+                else:
+                    v.zero_()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        return self
+
+    def __repr__(self):
+        return (f'ActorCritic[HIP gfx950](obs={self.obs_dim}, act={self.action_dim}, units={self.units}, LayerNorm+SiLU, '
+                f'dist={self.dist_type}, params={self.param_count})')

@@ -1,0 +1,683 @@
+// fp32 MFMA GEMM family for the PPO actor/critic towers (gfx950 only).
+//
+// One kernel template covers the three products of a Linear layer
+//   forward   Z[m][n]  = sum_k X[m][k]  * W[n][k]      (A: k contiguous, B: k contiguous)
+//   dgrad     dX[m][k] = sum_n dZ[m][n] * W[n][k]      (A: reduction contiguous, B: reduction is the row index)
+//   wgrad     dW[n][k] = sum_m dZ[m][n] * X[m][k]      (A and B: reduction is the row index)
+// on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains), with the element-wise work of the layer fused in:
+//   A/B prologue  : running-mean/std normalisation of raw observations, or LayerNorm-affine + SiLU of the
+//                   stored normalised activations (activations are kept in HBM as xhat = (z-mean)*rstd only)
+//   epilogue      : bias + LayerNorm statistics (forward), SiLU'/LayerNorm backward + column partial sums
+//                   (dgrad), plain partial slabs (wgrad, split over the batch), or the policy/value heads with
+//                   the PPO losses and their gradients.
+// Mirrors mineral/nets/mlp.py:50-77 (Linear -> LayerNorm -> SiLU) and torch autograd's backward of it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { LAY_K = 0, LAY_R = 1 };           // LAY_K: reduction index contiguous; LAY_R: reduction index = row
+enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2 };
+enum { EPI_LNFWD = 0, EPI_LNBWD = 1, EPI_SLAB = 2, EPI_HEADS_TRAIN = 3, EPI_HEADS_ACT = 4 };
+enum { DIST_NORMAL = 0, DIST_DREAMERV3 = 1 };
+
+#define MRL_LOG_SQRT_2PI 0.91893853320467274178f
+#define MRL_NMETRIC 12
+
+struct HeadsP {
+  // training (EPI_HEADS_TRAIN) inputs, all indexed by minibatch row
+  const float* actions;      // [M][A]
+  const float* old_neglogp;  // [M]
+  const float* adv;          // [M]
+  const float* returns;      // [M]
+  const float* value_preds;  // [M]
+  float* mu;                 // [M][A] in: old mu, out: new mu   (row stride mu_rs)
+  float* sigma;              // [M][A]
+  float* seeds[2];           // [M][32] per tower: d loss / d head pre-activations (zero padded)
+  double* metric_part;       // [gridDim.x][2][MRL_NMETRIC]
+  float* headb_part;         // [gridDim.x][2][32] column sums of the seeds (head bias gradients)
+  float inv_mb, e_clip, critic_coef, entropy_coef, bounds_coef;
+  int bounds_type, clip_value_loss;
+  // rollout (EPI_HEADS_ACT)
+  const float* noise;        // [M][A] standard normal
+  float* act_out;            // actions  -> act_out[row*out_rs + out_off + j]
+  float* act_clamped;        // [M][A] clamp(action,-1,1) or null
+  float* neglogp_out;        // [M]
+  float* value_out;          // [M]
+  const double* vrms_mean;   // value_rms state (fp64) or null when normalize_value is off
+  const double* vrms_var;
+  float vrms_eps;
+  int64_t out_rs, out_off;   // row stride / offset (floats) of act_out, mu, sigma in rollout mode
+  // shared
+  int act_dim, dist_type;
+  float minstd, maxstd;
+};
+
+struct GemmP {
+  const float* A[2];
+  const float* B[2];
+  int64_t lda, ldb;
+  int M, N, K;                 // GEMM sizes (M rows, N cols, K reduction); all loads are guarded by these
+  int Nt[2], Kt[2];            // per-tower valid N / K (the heads differ: 2*act_dim vs 1); 0 = use N / K
+  int tw0;                     // role of blockIdx.z == 0: 0 actor, 1 critic (critic-only launches)
+  int a_pro, b_pro;            // prologue applied to A / B elements, by the element's column in its matrix
+  const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU: gamma[f]
+  const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU: beta[f]
+  float clamp_lo, clamp_hi;
+  int ksplit;                  // EPI_SLAB: reduction rows per split (gridDim.y = n_tiles * n_split)
+  int n_tiles;                 // EPI_SLAB: number of N tiles
+  // EPI_LNFWD: out = xhat [M][N], rstd [M], bias [N]
+  // EPI_LNBWD: out = dz [M][N]; xhat/rstd/gamma/beta of the layer being differentiated; colpart slab
+  // EPI_SLAB : out = slab [n_split][M][N]
+  float* out[2];
+  int64_t ldo;
+  const float* bias[2];
+  float* rstd[2];              // LNFWD: written; LNBWD: read
+  const float* xhat[2];        // LNBWD
+  const float* gamma[2];       // LNBWD
+  const float* beta[2];        // LNBWD
+  float* colpart[2];           // LNBWD: [gridDim.x][3][N]  (dgamma, dbeta, dbias partial column sums)
+  float ln_eps;
+  HeadsP h;
+};
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
+__device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + expf(-y)); }
+
+__device__ __forceinline__ f32x4 apply_pro(f32x4 v, int pro, const float* p0, const float* p1, int col, float lo,
+                                           float hi) {
+  if (pro == PRO_NONE) return v;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p0 + col);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p1 + col);
+  f32x4 r;
+  if (pro == PRO_NORM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fminf(fmaxf((v[i] - a[i]) / b[i], lo), hi);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = silu_f(v[i] * a[i] + b[i]);
+  }
+  return r;
+}
+
+// sum over the 32 lanes of a half-wave (all lanes of the half receive the total)
+__device__ __forceinline__ float half_sum32(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ float group_sum16(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
+struct GemmCfg {
+  static constexpr int TM = BM / WGM / 32;
+  static constexpr int TN = BN / WGN / 32;
+  static constexpr int RA = (LA == LAY_K) ? BM : BK;   // rows / cols of the staged A tile
+  static constexpr int CA = (LA == LAY_K) ? BK : BM;
+  static constexpr int RB = (LB == LAY_K) ? BN : BK;
+  static constexpr int CB = (LB == LAY_K) ? BK : BN;
+  static constexpr int SA = CA + 4;                    // padded LDS row strides (floats)
+  static constexpr int SB = CB + 4;
+  static constexpr int A_F4 = (RA * CA / 4 + 255) / 256;
+  static constexpr int B_F4 = (RB * CB / 4 + 255) / 256;
+  static constexpr int LDS_TILES = RA * SA + RB * SB;
+  static constexpr int LDS_EPI = 2 * BM * WGN + 3 * BN * WGM + 64;   // cross-wave reduction scratch
+  static constexpr int LDS_FLOATS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
+  static_assert(WGM * WGN == 4, "256 threads = 4 waves");
+  static_assert(BM % (WGM * 32) == 0 && BN % (WGN * 32) == 0, "wave tiles are multiples of 32x32");
+  static_assert(BK % 8 == 0, "k sub-step is 8");
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
+  using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
+  constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  float* As = lds;
+  float* Bs = lds + C::RA * SA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tw = blockIdx.z;                 // index into the per-tower pointer arrays
+  const int Nv = p.Nt[tw] ? p.Nt[tw] : p.N;  // valid output columns / reduction length of this tower
+  const int m0 = blockIdx.x * BM;
+  int n0, kbeg = 0, kend = p.Kt[tw] ? p.Kt[tw] : p.K, split = 0;
+  if (EPI == EPI_SLAB) {
+    n0 = (blockIdx.y % p.n_tiles) * BN;
+    split = blockIdx.y / p.n_tiles;
+    kbeg = split * p.ksplit;
+    kend = min(p.K, kbeg + p.ksplit);
+  } else {
+    n0 = blockIdx.y * BN;
+  }
+  const float* __restrict__ Ag = p.A[tw];
+  const float* __restrict__ Bg = p.B[tw];
+  const float* pro0 = p.pro0[tw];
+  const float* pro1 = p.pro1[tw];
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 ra[C::A_F4], rb[C::B_F4];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < C::A_F4; ++i) {
+      int idx = tid + i * 256;
+      int r = idx / (C::CA / 4), c = (idx % (C::CA / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < C::RA * C::CA / 4) {
+        int grow = (LA == LAY_K) ? m0 + r : k0 + r;
+        int gcol = (LA == LAY_K) ? k0 + c : m0 + c;
+        int rlim = (LA == LAY_K) ? p.M : kend;
+        int clim = (LA == LAY_K) ? kend : p.M;
+        if (grow < rlim && gcol < clim) {
+          v = *reinterpret_cast<const f32x4*>(Ag + (int64_t)grow * p.lda + gcol);
+          v = apply_pro(v, p.a_pro, pro0, pro1, gcol, p.clamp_lo, p.clamp_hi);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_F4; ++i) {
+      int idx = tid + i * 256;
+      int r = idx / (C::CB / 4), c = (idx % (C::CB / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < C::RB * C::CB / 4) {
+        int grow = (LB == LAY_K) ? n0 + r : k0 + r;
+        int gcol = (LB == LAY_K) ? k0 + c : n0 + c;
+        int rlim = (LB == LAY_K) ? Nv : kend;
+        int clim = (LB == LAY_K) ? kend : Nv;
+        if (grow < rlim && gcol < clim) {
+          v = *reinterpret_cast<const f32x4*>(Bg + (int64_t)grow * p.ldb + gcol);
+          v = apply_pro(v, p.b_pro, pro0, pro1, gcol, p.clamp_lo, p.clamp_hi);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::A_F4; ++i) {
+      int idx = tid + i * 256;
+      int r = idx / (C::CA / 4), c = (idx % (C::CA / 4)) * 4;
+      if (idx < C::RA * C::CA / 4) *reinterpret_cast<f32x4*>(As + r * SA + c) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_F4; ++i) {
+      int idx = tid + i * 256;
+      int r = idx / (C::CB / 4), c = (idx % (C::CB / 4)) * 4;
+      if (idx < C::RB * C::CB / 4) *reinterpret_cast<f32x4*>(Bs + r * SB + c) = rb[i];
+    }
+  };
+
+  if (kbeg < kend) load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();                 // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) load_tiles(k0 + BK);   // prefetch into registers while the MFMAs run
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = wm * TM * 32 + i * 32 + l32;
+        if (LA == LAY_K) {
+          af[i] = *reinterpret_cast<const f32x4*>(As + row * SA + kk * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[i][j] = As[(kk * 8 + 4 * h + j) * SA + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int col = wn * TN * 32 + i * 32 + l32;
+        if (LB == LAY_K) {
+          bf[i] = *reinterpret_cast<const f32x4*>(Bs + col * SB + kk * 8 + 4 * h);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(kk * 8 + 4 * h + j) * SB + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // LDS is reused as reduction scratch below
+
+  // element (im, in, r) of this lane: row = rbase(im) + (r&3) + 8*(r>>2), col = cbase(in)
+  auto rowof = [&](int im, int r) { return wm * TM * 32 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; };
+  auto colof = [&](int in) { return wn * TN * 32 + in * 32 + l32; };
+
+  if constexpr (EPI == EPI_SLAB) {
+    float* out = p.out[tw] + (int64_t)split * p.M * p.ldo;
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        int col = n0 + colof(in);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = m0 + rowof(im, r);
+          if (row < p.M && col < p.N) out[(int64_t)row * p.ldo + col] = acc[im][in][r];
+        }
+      }
+  } else if constexpr (EPI == EPI_LNFWD) {
+    // bias, two-pass LayerNorm statistics over the full row (BN == N), store xhat and rstd
+    float* red1 = lds;                 // [BM][WGN]
+    float* red2 = lds + BM * WGN;      // [BM][WGN]
+    const float* bias = p.bias[tw];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      float b = bias[n0 + colof(in)];
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[im][in][r] += b;
+    }
+    const float invn = 1.0f / (float)BN;
+    float mean[TM][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int in = 0; in < TN; ++in) s += acc[im][in][r];
+        s = half_sum32(s);
+        if (WGN > 1) {
+          if (l32 == 0) red1[rowof(im, r) * WGN + wn] = s;
+        } else {
+          mean[im][r] = s * invn;
+        }
+      }
+    if (WGN > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < WGN; ++w) s += red1[rowof(im, r) * WGN + w];
+          mean[im][r] = s * invn;
+        }
+    }
+    float rstd[TM][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          float d = acc[im][in][r] - mean[im][r];
+          acc[im][in][r] = d;
+          s += d * d;
+        }
+        s = half_sum32(s);
+        if (WGN > 1) {
+          if (l32 == 0) red2[rowof(im, r) * WGN + wn] = s;
+        } else {
+          rstd[im][r] = 1.0f / sqrtf(s * invn + p.ln_eps);
+        }
+      }
+    if (WGN > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < WGN; ++w) s += red2[rowof(im, r) * WGN + w];
+          rstd[im][r] = 1.0f / sqrtf(s * invn + p.ln_eps);
+        }
+    }
+    float* out = p.out[tw];
+    float* rs = p.rstd[tw];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + rowof(im, r);
+        if (row < p.M) {
+#pragma unroll
+          for (int in = 0; in < TN; ++in) out[(int64_t)row * p.ldo + n0 + colof(in)] = acc[im][in][r] * rstd[im][r];
+          if (wn == 0 && l32 == 0) rs[row] = rstd[im][r];
+        }
+      }
+  } else if constexpr (EPI == EPI_LNBWD) {
+    // acc = d loss / d h with h = silu(y), y = xhat*gamma + beta, xhat = LayerNorm-normalised z.
+    // dy = dh * silu'(y); dxhat = dy*gamma; dz = rstd * (dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)).
+    float* red1 = lds;                         // [BM][WGN]  sum dxhat
+    float* red2 = lds + BM * WGN;              // [BM][WGN]  sum dxhat*xhat
+    float* cred = lds + 2 * BM * WGN;          // [WGM][3][BN] column partials
+    const float* xh = p.xhat[tw];
+    const float* gam = p.gamma[tw];
+    const float* bet = p.beta[tw];
+    const float invn = 1.0f / (float)BN;
+    float cg[TN], cb[TN], cz[TN];
+    float c1[TM][16], c2[TM][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c1[im][r] = c2[im][r] = 0.f;
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      int col = n0 + colof(in);
+      float g = gam[col], b = bet[col];
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = m0 + rowof(im, r);
+          float x = 0.f, dxh = 0.f;
+          if (row < p.M) {
+            x = xh[(int64_t)row * p.ldo + col];
+            float y = x * g + b;
+            float s = sigmoid_f(y);
+            float dy = acc[im][in][r] * (s * (1.0f + y * (1.0f - s)));
+            sg += dy * x;
+            sb += dy;
+            dxh = dy * g;
+          }
+          acc[im][in][r] = dxh;
+          c1[im][r] += dxh;
+          c2[im][r] += dxh * x;
+        }
+      cg[in] = sg;
+      cb[in] = sb;
+    }
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s1 = half_sum32(c1[im][r]), s2 = half_sum32(c2[im][r]);
+        if (WGN > 1) {
+          if (l32 == 0) {
+            red1[rowof(im, r) * WGN + wn] = s1;
+            red2[rowof(im, r) * WGN + wn] = s2;
+          }
+        } else {
+          c1[im][r] = s1 * invn;
+          c2[im][r] = s2 * invn;
+        }
+      }
+    if (WGN > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WGN; ++w) {
+            s1 += red1[rowof(im, r) * WGN + w];
+            s2 += red2[rowof(im, r) * WGN + w];
+          }
+          c1[im][r] = s1 * invn;
+          c2[im][r] = s2 * invn;
+        }
+    }
+    float* out = p.out[tw];
+    const float* rs = p.rstd[tw];
+    float rstd[TM][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + rowof(im, r);
+        rstd[im][r] = row < p.M ? rs[row] : 0.f;
+      }
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      int col = n0 + colof(in);
+      float sz = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = m0 + rowof(im, r);
+          if (row < p.M) {
+            float x = xh[(int64_t)row * p.ldo + col];
+            float dz = rstd[im][r] * (acc[im][in][r] - c1[im][r] - x * c2[im][r]);
+            out[(int64_t)row * p.ldo + col] = dz;
+            sz += dz;
+          }
+        }
+      cz[in] = sz;
+    }
+    // column partial sums: combine the two half-waves, then the WGM waves that share a column
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      float g = cg[in] + __shfl_xor(cg[in], 32);
+      float b = cb[in] + __shfl_xor(cb[in], 32);
+      float z = cz[in] + __shfl_xor(cz[in], 32);
+      if (h == 0) {
+        int col = colof(in);
+        cred[(wm * 3 + 0) * BN + col] = g;
+        cred[(wm * 3 + 1) * BN + col] = b;
+        cred[(wm * 3 + 2) * BN + col] = z;
+      }
+    }
+    __syncthreads();
+    float* cp = p.colpart[tw] + (int64_t)blockIdx.x * 3 * BN;
+    for (int i = tid; i < 3 * BN; i += 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) s += cred[w * 3 * BN + i];
+      cp[i] = s;
+    }
+  } else if constexpr (EPI == EPI_HEADS_TRAIN || EPI == EPI_HEADS_ACT) {
+    static_assert(TN == 1 && WGN == 1 && TM == 1, "heads use a 32-wide tile, one 32x32 block per wave");
+    const HeadsP& hp = p.h;
+    const int A = hp.act_dim;
+    const float bias = (l32 < Nv) ? p.bias[tw][l32] : 0.f;
+    const bool actor = (tw + p.tw0 == 0);
+    float cs0 = 0.f, cs1 = 0.f;              // column sums of the seeds (bias gradients)
+    double macc[MRL_NMETRIC];
+#pragma unroll
+    for (int i = 0; i < MRL_NMETRIC; ++i) macc[i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + rowof(0, r);
+      const bool rv = row < p.M;
+      const int rowc = rv ? row : 0;
+      float o = acc[0][0][r] + bias;
+      if (actor) {
+        // lanes j < A hold mu_head[j]; lanes A <= j < 2A hold logstd[j-A] (mineral/agents/ppo/models.py:140-151)
+        float ls = __shfl(o, (lane & 32) + ((l32 + A) & 31));
+        const bool jv = l32 < A;
+        float mu, sg = 0.f, sigma;
+        if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
+          mu = tanhf(o);
+          sg = sigmoid_f(ls + 2.0f);
+          sigma = (hp.maxstd - hp.minstd) * sg + hp.minstd;
+        } else {                                   // mineral/nets/dist.py:32-34
+          mu = o;
+          sigma = expf(ls);
+        }
+        if (!jv) { mu = 0.f; sigma = 1.f; }
+        const float logsig = logf(sigma);
+        if constexpr (EPI == EPI_HEADS_ACT) {
+          // mineral/agents/ppo/models.py:115-117 with sample = mu + sigma * noise
+          float eps = jv ? hp.noise[(int64_t)rowc * A + l32] : 0.f;
+          float a = mu + sigma * eps;
+          float d = a - mu;
+          float nl = jv ? (d * d) / (2.0f * sigma * sigma) + logsig + MRL_LOG_SQRT_2PI : 0.f;
+          nl = group_sum16(nl);
+          if (rv && jv) {
+            int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + l32;
+            hp.act_out[o_idx] = a;
+            hp.mu[o_idx] = mu;
+            hp.sigma[o_idx] = sigma;
+            if (hp.act_clamped) hp.act_clamped[(int64_t)row * A + l32] = fminf(fmaxf(a, -1.0f), 1.0f);
+          }
+          if (rv && l32 == 0) hp.neglogp_out[row] = nl;
+        } else {
+          // mineral/agents/ppo/models.py:93-107 and mineral/agents/ppo/ppo.py:277-303
+          float a = jv ? hp.actions[(int64_t)rowc * A + l32] : 0.f;
+          float omu = jv ? hp.mu[(int64_t)rowc * A + l32] : 0.f;
+          float osg = jv ? hp.sigma[(int64_t)rowc * A + l32] : 1.f;
+          float d = a - mu;
+          float var2 = 2.0f * sigma * sigma;
+          float nl = jv ? (d * d) / var2 + logsig + MRL_LOG_SQRT_2PI : 0.f;
+          float ent = jv ? 0.5f + MRL_LOG_SQRT_2PI + logsig : 0.f;
+          float bl = 0.f, dbl = 0.f;
+          if (jv) {
+            if (hp.bounds_type == 0) {             // 'bound' (ppo.py:480-484)
+              float hi = fmaxf(mu - 1.1f, 0.f), lo = fminf(mu + 1.1f, 0.f);
+              bl = lo * lo + hi * hi;
+              dbl = 2.0f * hi + 2.0f * lo;
+            } else {                               // 'reg' (ppo.py:485-487)
+              bl = mu * mu;
+              dbl = 2.0f * mu;
+            }
+          }
+          float kl = 0.f;
+          if (jv) {                                // ppo.py:492-498, p0 = new, p1 = stored
+            float dm = omu - mu;
+            kl = logf(osg / sigma + 1e-5f) + (sigma * sigma + dm * dm) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+          }
+          nl = group_sum16(nl);
+          ent = group_sum16(ent);
+          bl = group_sum16(bl);
+          kl = group_sum16(kl);
+          float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
+          float ratio = expf(oldnl - nl);                        // ppo.py:455
+          float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
+          float rc = fminf(fmaxf(ratio, lo_r), hi_r);
+          float x1 = -(adv * ratio), x2 = -(adv * rc);
+          float al = fmaxf(x1, x2);
+          float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;
+          float dratio = (x1 > x2) ? -adv : (x1 < x2) ? -adv * inr : 0.5f * (-adv) + 0.5f * (-adv * inr);
+          float dnl = hp.inv_mb * dratio * (-ratio);
+          float dmu = dnl * (-d / (sigma * sigma)) + hp.bounds_coef * hp.inv_mb * dbl;
+          float dsig = dnl * (-(d * d) / (sigma * sigma * sigma) + 1.0f / sigma) - hp.entropy_coef * hp.inv_mb / sigma;
+          float s_mu, s_ls;
+          if (hp.dist_type == DIST_DREAMERV3) {
+            s_mu = dmu * (1.0f - mu * mu);
+            s_ls = dsig * (hp.maxstd - hp.minstd) * sg * (1.0f - sg);
+          } else {
+            s_mu = dmu;
+            s_ls = dsig * sigma;
+          }
+          if (rv) {
+            float* sd = hp.seeds[0] + (int64_t)row * 32;
+            if (jv) {
+              sd[l32] = s_mu;
+              sd[A + l32] = s_ls;
+              cs0 += s_mu;
+              cs1 += s_ls;
+              hp.mu[(int64_t)row * A + l32] = mu;              // experience.py:83-87 write-back
+              hp.sigma[(int64_t)row * A + l32] = sigma;
+            } else if (l32 >= 2 * A) {
+              sd[l32] = 0.f;
+            }
+            if (l32 == 0) {
+              macc[0] += al;
+              macc[1] += ent;
+              macc[2] += bl;
+              macc[3] += kl;
+              macc[4] += (fabsf(ratio - 1.0f) > hp.e_clip) ? 1.0 : 0.0;
+            }
+          }
+        }
+      } else {
+        // critic: lane 0 of each half holds the value (models.py:147-149)
+        if constexpr (EPI == EPI_HEADS_ACT) {
+          if (rv && l32 == 0) {
+            float v = o;
+            if (hp.vrms_mean) {                    // normalizers.py:70-73 (clamp first, then un-scale)
+              v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
+              v = sqrtf((float)hp.vrms_var[0] + hp.vrms_eps) * v + (float)hp.vrms_mean[0];
+            }
+            hp.value_out[row] = v;
+          }
+        } else {
+          float ret = hp.returns[rowc], vp = hp.value_preds[rowc];
+          float v = o;
+          float e1 = v - ret;
+          float cl = e1 * e1, dv = 2.0f * e1;      // ppo.py:466-473
+          if (hp.clip_value_loss) {
+            float dvp = v - vp;
+            float vc = vp + fminf(fmaxf(dvp, -hp.e_clip), hp.e_clip);
+            float e2 = vc - ret;
+            float c2v = e2 * e2;
+            float in2 = (dvp >= -hp.e_clip && dvp <= hp.e_clip) ? 1.0f : 0.0f;
+            float d2 = 2.0f * e2 * in2;
+            dv = (cl > c2v) ? dv : (cl < c2v) ? d2 : 0.5f * dv + 0.5f * d2;
+            cl = fmaxf(cl, c2v);
+          }
+          float s_v = hp.inv_mb * 0.5f * hp.critic_coef * dv;   // ppo.py:285
+          if (rv) {
+            float* sd = hp.seeds[1] + (int64_t)row * 32;
+            sd[l32] = (l32 == 0) ? s_v : 0.f;
+            if (l32 == 0) {
+              cs0 += s_v;
+              macc[5] += cl;
+              double dr = (double)ret - (double)v;
+              macc[6] += dr;
+              macc[7] += dr * dr;
+              macc[8] += ret;
+              macc[9] += (double)ret * ret;
+            }
+          }
+        }
+      }
+    }
+    if constexpr (EPI == EPI_HEADS_TRAIN) {
+      double* red = reinterpret_cast<double*>(lds);     // [8][MRL_NMETRIC]
+      float* csum = lds + 256;                           // [8][64]
+      csum[(wave * 2 + h) * 64 + l32] = cs0;
+      csum[(wave * 2 + h) * 64 + 32 + l32] = cs1;
+      if (l32 == 0) {
+#pragma unroll
+        for (int i = 0; i < MRL_NMETRIC; ++i) red[(wave * 2 + h) * MRL_NMETRIC + i] = macc[i];
+      }
+      __syncthreads();
+      if (tid < MRL_NMETRIC) {
+        double s = 0.0;
+        for (int w = 0; w < 8; ++w) s += red[w * MRL_NMETRIC + tid];
+        hp.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
+      }
+      if (tid < 32) {
+        const int src = actor ? (tid < A ? tid : (tid < 2 * A ? 32 + tid - A : -1)) : (tid == 0 ? 0 : -1);
+        float s = 0.f;
+        if (src >= 0)
+          for (int w = 0; w < 8; ++w) s += csum[w * 64 + src];
+        hp.headb_part[((int64_t)blockIdx.x * 2 + tw) * 32 + tid] = s;
+      }
+    }
+  }
+}
+
+}  // namespace mrl

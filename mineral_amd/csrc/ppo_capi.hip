@@ -1,0 +1,911 @@
+// C ABI of the PPO hot path: streaming kernels (rollout write, GAE scan, running moments, Adam) and the launch
+// sequences that drive the fp32 MFMA GEMM family of gemm.hip.h.  gfx950 only.
+#include "../../include/mineral_ppo.h"
+#include "gemm.hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+using namespace mrl;
+
+static thread_local char g_err[512] = "";
+
+#define MRL_FAIL(code, ...)                      \
+  do {                                           \
+    snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+    return (code);                               \
+  } while (0)
+
+#define MRL_CHECK_LAUNCH(what)                                                            \
+  do {                                                                                    \
+    hipError_t e__ = hipGetLastError();                                                   \
+    if (e__ != hipSuccess) MRL_FAIL(MRL_EHIP, "%s: %s", what, hipGetErrorString(e__));    \
+  } while (0)
+
+extern "C" const char* mrl_last_error(void) { return g_err; }
+extern "C" int mrl_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameter / workspace layouts
+// ---------------------------------------------------------------------------------------------------------------
+static inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+static inline int64_t align64(int64_t x) { return (x + 63) & ~int64_t(63); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct ParamLayout {
+  int64_t W[2][MRL_MAX_LAYERS], b[2][MRL_MAX_LAYERS], g[2][MRL_MAX_LAYERS], be[2][MRL_MAX_LAYERS];
+  int64_t Wh[2], bh[2];   // heads: actor [2A][U] / [2A], critic [1][U] / [1]
+  int64_t total;
+  int in_dim[MRL_MAX_LAYERS];
+};
+
+static int check_net(const mrl_net* net) {
+  if (!net) MRL_FAIL(MRL_EINVAL, "net is NULL");
+  if (net->n_layers < 1 || net->n_layers > MRL_MAX_LAYERS) MRL_FAIL(MRL_EINVAL, "n_layers %d not in 1..%d", net->n_layers, MRL_MAX_LAYERS);
+  if (net->obs_dim < 4 || net->obs_dim % 4) MRL_FAIL(MRL_EINVAL, "obs_dim %d must be a positive multiple of 4", net->obs_dim);
+  if (net->act_dim < 1 || net->act_dim > 16) MRL_FAIL(MRL_EINVAL, "act_dim %d not in 1..16", net->act_dim);
+  for (int l = 0; l < net->n_layers; ++l) {
+    int u = net->units[l];
+    if (!(u == 32 || u == 64 || u == 128 || u == 256 || u == 512)) MRL_FAIL(MRL_EINVAL, "units[%d]=%d must be 32/64/128/256/512", l, u);
+  }
+  if (net->dist_type != MRL_DIST_NORMAL && net->dist_type != MRL_DIST_DREAMERV3_NORMAL) MRL_FAIL(MRL_EINVAL, "dist_type %d unsupported", net->dist_type);
+  return MRL_OK;
+}
+
+static void param_layout(const mrl_net* net, ParamLayout* L) {
+  int64_t o = 0;
+  for (int tw = 0; tw < 2; ++tw) {
+    int in = net->obs_dim;
+    for (int l = 0; l < net->n_layers; ++l) {
+      int u = net->units[l];
+      L->in_dim[l] = in;
+      L->W[tw][l] = o; o = align4(o + (int64_t)u * in);
+      L->b[tw][l] = o; o = align4(o + u);
+      L->g[tw][l] = o; o = align4(o + u);
+      L->be[tw][l] = o; o = align4(o + u);
+      in = u;
+    }
+  }
+  int U = net->units[net->n_layers - 1], A = net->act_dim;
+  L->Wh[0] = o; o = align4(o + (int64_t)2 * A * U);
+  L->bh[0] = o; o = align4(o + 2 * A);
+  L->Wh[1] = o; o = align4(o + U);
+  L->bh[1] = o; o = align4(o + 1);
+  L->total = o;
+}
+
+extern "C" int64_t mrl_param_count(const mrl_net* net) {
+  if (check_net(net)) return MRL_EINVAL;
+  ParamLayout L;
+  param_layout(net, &L);
+  return L.total;
+}
+
+extern "C" int mrl_param_offsets(const mrl_net* net, int64_t* offs, int32_t* n) {
+  if (check_net(net)) return MRL_EINVAL;
+  if (!offs || !n) MRL_FAIL(MRL_EINVAL, "NULL output");
+  ParamLayout L;
+  param_layout(net, &L);
+  int k = 0;
+  for (int tw = 0; tw < 2; ++tw)
+    for (int l = 0; l < net->n_layers; ++l) {
+      offs[k++] = L.W[tw][l]; offs[k++] = L.b[tw][l]; offs[k++] = L.g[tw][l]; offs[k++] = L.be[tw][l];
+    }
+  offs[k++] = L.Wh[0]; offs[k++] = L.bh[0]; offs[k++] = L.Wh[1]; offs[k++] = L.bh[1];
+  *n = k;
+  return MRL_OK;
+}
+
+static inline int fwd_bm(int n) { return n == 512 ? 64 : 128; }   // rows per block of the full-row (LayerNorm) tiles
+
+struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
+
+static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
+  WgradPlan w;
+  w.bm = (gm <= 32) ? 32 : 128;
+  w.bn = (w.bm == 32) ? 128 : (gn <= 64 ? 64 : 128);
+  w.tiles_m = (int)cdiv(gm, w.bm);
+  w.tiles_n = (int)cdiv(gn, w.bn);
+  int64_t want = cdiv(768, (int64_t)w.tiles_m * w.tiles_n * 2);
+  int64_t ks = cdiv(cdiv(rows, want), 16) * 16;
+  if (ks < 64) ks = 64;
+  w.ksplit = (int)ks;
+  w.nsplit = (int)cdiv(rows, ks);
+  return w;
+}
+
+struct Workspace {
+  // offsets in floats from the workspace base
+  int64_t xhat[2][MRL_MAX_LAYERS], rstd[2][MRL_MAX_LAYERS], dz[2][MRL_MAX_LAYERS];
+  int64_t seeds[2];
+  int64_t colpart[2][MRL_MAX_LAYERS];
+  int64_t slab[2][MRL_MAX_LAYERS], slab_h[2];
+  int64_t metric_part;   // doubles, 8-byte aligned
+  int64_t headb_part;    // [rows/128][2][32] column sums of the head seeds (bias gradients)
+  int64_t small;         // misc: obs mean/std f32 (2*obs_dim), partial sums
+  int64_t total;
+  WgradPlan wp[MRL_MAX_LAYERS], wph;
+  int rowblocks[MRL_MAX_LAYERS];
+};
+
+static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
+  int64_t o = 0;
+  ParamLayout L;
+  param_layout(net, &L);
+  int U = net->units[net->n_layers - 1];
+  for (int tw = 0; tw < 2; ++tw) {
+    for (int l = 0; l < net->n_layers; ++l) {
+      int u = net->units[l];
+      w->xhat[tw][l] = o; o = align64(o + rows * u);
+      w->rstd[tw][l] = o; o = align64(o + rows);
+      w->dz[tw][l] = o; o = align64(o + rows * u);
+      w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));
+      w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
+      w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
+      w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
+    }
+    w->seeds[tw] = o; o = align64(o + rows * 32);
+    w->wph = wgrad_plan(32, U, rows);
+    w->slab_h[tw] = o; o = align64(o + (int64_t)w->wph.nsplit * 32 * U);
+  }
+  w->metric_part = o; o = align64(o + 2 * cdiv(rows, 128) * 2 * MRL_NMETRIC + 64);
+  w->headb_part = o; o = align64(o + cdiv(rows, 128) * 64);
+  w->small = o; o = align64(o + 4096 + 2 * (int64_t)net->obs_dim + 16 * cdiv(rows, 64));
+  w->total = o;
+}
+
+extern "C" int64_t mrl_workspace_bytes(const mrl_net* net, int64_t rows) {
+  if (check_net(net)) return MRL_EINVAL;
+  if (rows < 1) MRL_FAIL(MRL_EINVAL, "rows %lld < 1", (long long)rows);
+  Workspace w;
+  workspace_layout(net, rows, &w);
+  return w.total * 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM launch helpers
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
+static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI>), grid, dim3(256), 0, s, p);
+}
+
+// full-row tiles, selected by the output width
+#define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, p, towers, s)                                                  \
+  do {                                                                                                             \
+    switch (N) {                                                                                                   \
+      case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;      \
+      case 256: launch_gemm<128, 256, BKBIG, 2, 2, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break; \
+      case 128: launch_gemm<128, 128, BKBIG, 2, 2, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break; \
+      case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+      default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+    }                                                                                                              \
+  } while (0)
+
+static void launch_wgrad(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
+  dim3 grid(w.tiles_m, w.tiles_n * w.nsplit, towers);
+  if (w.bm == 32)
+    launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+  else if (w.bn == 64)
+    launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+  else
+    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+}
+
+// Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
+static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
+                              const float* x, int64_t rows, const float* obs_mean, const float* obs_std, float lo, float hi,
+                              int tw0, int towers, hipStream_t s) {
+  for (int l = 0; l < net->n_layers; ++l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    int u = net->units[l], in = L.in_dim[l];
+    for (int t = 0; t < towers; ++t) {
+      int tw = tw0 + t;
+      p.A[t] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
+      p.B[t] = params + L.W[tw][l];
+      p.pro0[t] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
+      p.pro1[t] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
+      p.out[t] = ws + W.xhat[tw][l];
+      p.rstd[t] = ws + W.rstd[tw][l];
+      p.bias[t] = params + L.b[tw][l];
+    }
+    p.lda = in; p.ldb = in; p.ldo = u;
+    p.M = (int)rows; p.N = u; p.K = in;
+    p.Nt[0] = p.Nt[1] = u; p.Kt[0] = p.Kt[1] = in;
+    p.a_pro = (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU;
+    p.b_pro = PRO_NONE;
+    p.clamp_lo = lo; p.clamp_hi = hi;
+    p.ln_eps = net->ln_eps;
+    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, p, towers, s);
+  }
+}
+
+static void fill_heads_common(const mrl_net* net, HeadsP* h) {
+  h->act_dim = net->act_dim;
+  h->dist_type = net->dist_type == MRL_DIST_DREAMERV3_NORMAL ? DIST_DREAMERV3 : DIST_NORMAL;
+  h->minstd = net->minstd;
+  h->maxstd = net->maxstd;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// streaming kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int cols4,
+                                 int64_t dst_row_stride4, int64_t dst_off4) {
+  // src [rows][cols] contiguous -> dst[row*stride + off + c]; all in float4 units
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = rows * cols4;
+  for (; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / cols4;
+    int c = (int)(i % cols4);
+    reinterpret_cast<f32x4*>(dst)[r * dst_row_stride4 + dst_off4 + c] = reinterpret_cast<const f32x4*>(src)[i];
+  }
+}
+
+__global__ void rms_to_f32_kernel(const double* mean, const double* var, float eps, int n, float* mean_f, float* std_f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    mean_f[i] = (float)mean[i];
+    std_f[i] = sqrtf((float)var[i] + eps);
+  }
+}
+
+__global__ void rollout_write_kernel(float* __restrict__ rewards_t, uint8_t* __restrict__ dones_t,
+                                     const float* __restrict__ values_t, const float* __restrict__ r,
+                                     const uint8_t* __restrict__ dones, const uint8_t* __restrict__ time_outs, int64_t n,
+                                     float scale, float gamma) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = __fmul_rn(r[i], scale);                                   // reward_shaper.py:10-12
+  if (time_outs) {                                                    // ppo.py:159-162
+    float b = __fmul_rn(__fmul_rn(gamma, values_t[i]), time_outs[i] ? 1.0f : 0.0f);
+    s = __fadd_rn(s, b);
+  }
+  rewards_t[i] = s;
+  dones_t[i] = dones[i] ? 1 : 0;
+}
+
+// GAE(lambda) reverse scan for 64 consecutive envs per block (one env per lane), then a coalesced write of the
+// env-major flat arrays through an LDS transpose.  experience.py:96-108 (+ flatten of :110-118).
+__global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                 const uint8_t* __restrict__ dones, const float* __restrict__ neglogp_tn,
+                                                 const float* __restrict__ last_values, int64_t N, int T, float gamma,
+                                                 float gamma_tau, float* __restrict__ returns_f, float* __restrict__ values_f,
+                                                 float* __restrict__ adv_f, float* __restrict__ neglogp_f,
+                                                 double* __restrict__ part) {
+  extern __shared__ float sm[];   // 4 tiles [64][T+1]
+  const int S = T + 1;
+  float* s_ret = sm;
+  float* s_val = sm + 64 * S;
+  float* s_adv = sm + 2 * 64 * S;
+  float* s_nlp = sm + 3 * 64 * S;
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * 64;
+  const int64_t n = n0 + lane;
+  double sa = 0, sa2 = 0, sv = 0, sv2 = 0, sr = 0, sr2 = 0;
+  if (n < N) {
+    float next_v = last_values[n];
+    float last = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+      int64_t i = (int64_t)t * N + n;
+      float v = values[i];
+      float nnt = 1.0f - (float)dones[i];
+      // delta = r + gamma*next_values*nnt - v ; adv = delta + (gamma*tau)*nnt*last   (unfused, as torch evaluates it)
+      float delta = __fsub_rn(__fadd_rn(rewards[i], __fmul_rn(__fmul_rn(gamma, next_v), nnt)), v);
+      last = __fadd_rn(delta, __fmul_rn(__fmul_rn(gamma_tau, nnt), last));
+      float ret = __fadd_rn(last, v);
+      s_ret[lane * S + t] = ret;
+      s_val[lane * S + t] = v;
+      float adv = __fsub_rn(ret, v);      // experience.py:119: advantages = returns - values
+      s_adv[lane * S + t] = adv;
+      s_nlp[lane * S + t] = neglogp_tn[i];
+      sa += adv; sa2 += (double)adv * adv;
+      sv += v; sv2 += (double)v * v;
+      sr += ret; sr2 += (double)ret * ret;
+      next_v = v;
+    }
+  }
+  double vals[6] = {sa, sa2, sv, sv2, sr, sr2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double x = vals[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    vals[k] = x;
+  }
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) part[(int64_t)blockIdx.x * 6 + k] = vals[k];
+  __syncthreads();
+  int64_t nvalid = (N - n0 < 64) ? (N - n0) : 64;
+  int64_t cnt = nvalid * T;
+  for (int64_t j = lane; j < cnt; j += 64) {
+    int e = (int)(j / T), t = (int)(j % T);
+    int64_t o = n0 * T + j;
+    returns_f[o] = s_ret[e * S + t];
+    values_f[o] = s_val[e * S + t];
+    adv_f[o] = s_adv[e * S + t];
+    neglogp_f[o] = s_nlp[e * S + t];
+  }
+}
+
+// One block: whole-batch advantage statistics and the two-stage value_rms update (ppo.py:175-183,
+// experience.py:119-120).  stats: [0] adv mean [1] adv std [2,3] value mean/std after update 1 [4,5] after update 2.
+__global__ __launch_bounds__(256) void gae_stats_kernel(const double* __restrict__ part, int nblocks, double count,
+                                                        double* rmean, double* rvar, double* rcount, float eps,
+                                                        float* __restrict__ stats) {
+  __shared__ double red[6][256];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+    for (int k = 0; k < 6; ++k) acc[k] += part[(int64_t)b * 6 + k];
+  for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[6];
+    for (int k = 0; k < 6; ++k) {
+      double x = 0;
+      for (int i = 0; i < 256; ++i) x += red[k][i];
+      s[k] = x;
+    }
+    double n = count;
+    double am = s[0] / n;
+    double avar = (s[1] - s[0] * s[0] / n) / (n - 1.0);
+    stats[0] = (float)am;
+    stats[1] = (float)sqrt(avar > 0 ? avar : 0.0);
+    if (rmean) {
+      double mean = rmean[0], var = rvar[0], cnt = rcount[0];
+      for (int stage = 0; stage < 2; ++stage) {
+        double sx = s[2 + 2 * stage], sx2 = s[3 + 2 * stage];
+        // batch moments are fp32 tensors in the reference (x.mean(0), x.var(0, correction=1))
+        double bm = (double)(float)(sx / n);
+        double bv = (double)(float)((sx2 - sx * sx / n) / (n - 1.0));
+        double delta = bm - mean, tot = cnt + n;
+        double new_mean = mean + delta * n / tot;
+        double m2 = var * cnt + bv * n + delta * delta * cnt * n / tot;
+        mean = new_mean; var = m2 / tot; cnt = tot;
+        stats[2 + 2 * stage] = (float)mean;
+        stats[3 + 2 * stage] = sqrtf((float)var + eps);
+      }
+      rmean[0] = mean; rvar[0] = var; rcount[0] = cnt;
+    }
+  }
+}
+
+__global__ void gae_normalize_kernel(float* __restrict__ adv, float* __restrict__ values, float* __restrict__ returns,
+                                     const float* __restrict__ stats, int64_t n, int norm_value, float lo, float hi) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  adv[i] = __fdiv_rn(__fsub_rn(adv[i], stats[0]), __fadd_rn(stats[1], 1e-8f));   // experience.py:120
+  if (norm_value) {
+    values[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(values[i], stats[2]), stats[3]), lo), hi);
+    returns[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(returns[i], stats[4]), stats[5]), lo), hi);
+  }
+}
+
+// Column sums / sums of squares (fp64) of a chunk of rows of one group.  grid = (chunks, groups).
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, int cols, int64_t group_rows,
+                                                              int64_t chunk_rows, double* __restrict__ part) {
+  extern __shared__ double smd[];   // [2][rowlanes][cols]
+  const int rowlanes = 256 / cols > 0 ? 256 / cols : 1;
+  const int c = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int64_t g = blockIdx.y, ch = blockIdx.x;
+  int64_t r0 = ch * chunk_rows, r1 = r0 + chunk_rows;
+  if (r1 > group_rows) r1 = group_rows;
+  double s = 0, s2 = 0;
+  if (rl < rowlanes) {
+    const float* base = x + (g * group_rows) * cols;
+    for (int64_t r = r0 + rl; r < r1; r += rowlanes) {
+      float v = base[r * cols + c];
+      s += v;
+      s2 += (double)v * v;
+    }
+    smd[rl * cols + c] = s;
+    smd[(rowlanes + rl) * cols + c] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < cols) {
+    double a = 0, b = 0;
+    for (int i = 0; i < rowlanes; ++i) {
+      a += smd[i * cols + threadIdx.x];
+      b += smd[(rowlanes + i) * cols + threadIdx.x];
+    }
+    double* o = part + ((g * gridDim.x + ch) * 2) * cols;
+    o[threadIdx.x] = a;
+    o[cols + threadIdx.x] = b;
+  }
+}
+
+__global__ void moments_final_kernel(const double* __restrict__ part, int chunks, int cols, double n, int correction,
+                                     float* __restrict__ mean_out, float* __restrict__ var_out) {
+  int c = threadIdx.x + blockIdx.x * blockDim.x;
+  int64_t g = blockIdx.y;
+  if (c >= cols) return;
+  double s = 0, s2 = 0;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const double* o = part + ((g * chunks + ch) * 2) * cols;
+    s += o[c];
+    s2 += o[cols + c];
+  }
+  double m = s / n;
+  double v = (s2 - s * s / n) / (n - (double)correction);
+  mean_out[g * cols + c] = (float)m;
+  var_out[g * cols + c] = (float)(v > 0 ? v : 0.0);
+}
+
+__global__ void rms_merge_kernel(double* mean, double* var, double* count, const float* __restrict__ bmean,
+                                 const float* __restrict__ bvar, double bcount, int n, float eps, float* mean_f,
+                                 float* std_f) {
+  // normalizers.py:44-55, one thread per feature; the count is shared so it is read before anyone writes it
+  int i = threadIdx.x + blockIdx.x * blockDim.x;
+  double cnt = count[0];
+  __syncthreads();
+  if (i < n) {
+    double m = mean[i], v = var[i];
+    double delta = (double)bmean[i] - m;
+    double tot = cnt + bcount;
+    double nm = m + delta * bcount / tot;
+    double m2 = v * cnt + (double)bvar[i] * bcount + delta * delta * cnt * bcount / tot;
+    double nv = m2 / tot;
+    mean[i] = nm;
+    var[i] = nv;
+    if (mean_f) mean_f[i] = (float)nm;
+    if (std_f) std_f[i] = sqrtf((float)nv + eps);
+  }
+  if (i == 0) count[0] = cnt + bcount;
+}
+
+__global__ void rms_normalize_kernel(const double* __restrict__ mean, const double* __restrict__ var, float eps, float lo,
+                                     float hi, const float* __restrict__ x, float* __restrict__ y, int64_t total, int cols,
+                                     int unnorm) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % cols);
+  float m = (float)mean[c];
+  float s = sqrtf((float)var[c] + eps);
+  float v = x[i];
+  if (unnorm) {
+    v = fminf(fmaxf(v, lo), hi);                       // normalizers.py:70-73
+    y[i] = __fadd_rn(__fmul_rn(s, v), m);
+  } else {
+    y[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, m), s), lo), hi);   // normalizers.py:65-68
+  }
+}
+
+// Sum `nslabs` partial slabs into the flat gradient.  One descriptor per gradient tensor; grid.y = descriptor.
+struct ReduceDesc { const float* src; float* dst; int64_t count; int64_t stride; int nslabs; };
+#define MRL_MAX_RDESC 48
+struct ReduceTable { ReduceDesc d[MRL_MAX_RDESC]; int n; };
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
+  const ReduceDesc d = tab.d[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < d.nslabs; ++k) s += d.src[k * d.stride + i];
+    d.dst[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void metrics_final_kernel(const double* __restrict__ part, int nblocks, double mb,
+                                                           float critic_coef, float entropy_coef, float bounds_coef,
+                                                           double* __restrict__ out) {
+  // part [nblocks][2][NMETRIC]; fixed-order sums so results are reproducible
+  __shared__ double s[MRL_NMETRIC];
+  if (threadIdx.x < MRL_NMETRIC) {
+    double a = 0;
+    for (int b = 0; b < nblocks; ++b) a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + threadIdx.x] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + threadIdx.x];
+    s[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a_loss = s[0] / mb, ent = s[1] / mb, b_loss = s[2] / mb, kl = s[3] / mb, cf = s[4] / mb, c_loss = s[5] / mb;
+    double var_d = (s[7] - s[6] * s[6] / mb) / (mb - 1.0);
+    double var_r = (s[9] - s[8] * s[8] / mb) / (mb - 1.0);
+    double ev = 1.0 - var_d / (var_r + 1e-8);          // ppo.py:475
+    ev = ev < 0 ? 0 : (ev > 1 ? 1 : ev);
+    out[0] = a_loss; out[1] = ent; out[2] = b_loss; out[3] = kl; out[4] = cf; out[5] = c_loss; out[6] = ev;
+    out[7] = a_loss + 0.5 * c_loss * critic_coef - ent * entropy_coef + b_loss * bounds_coef;   // ppo.py:285
+    out[8] = out[9] = out[10] = out[11] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ g, int64_t n, float scale,
+                                                               double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = g[i] * scale;
+    s += (double)v * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+struct AdamArgs {
+  float lr_wd_mul;      // 1 - lr*wd           (AdamW)
+  float l2;             // weight decay folded into the gradient (Adam)
+  float one_m_b1, b2, one_m_b2;
+  float bc2_sqrt, eps, neg_step_size;
+  float max_norm, grad_scale;
+  int adamw, nparts;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const double* __restrict__ norm_part,
+                                                   const AdamArgs a, float* __restrict__ gnorm_out) {
+  // every block re-reduces the (<= 256) norm partials in the same fixed order
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < a.nparts; ++i) s += norm_part[i];
+    float norm = (float)sqrt(s);
+    float coef = 1.0f;
+    if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);   // torch clip_grad_norm_
+    s_coef = coef;
+    if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = norm;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = __fmul_rn(__fmul_rn(g[i], a.grad_scale), coef);
+    float pi = p[i];
+    if (a.adamw) pi = __fmul_rn(pi, a.lr_wd_mul);
+    else if (a.l2 != 0.f) gi = __fadd_rn(gi, __fmul_rn(a.l2, pi));
+    float mi = m[i], vi = v[i];
+    mi = __fadd_rn(mi, __fmul_rn(a.one_m_b1, __fsub_rn(gi, mi)));                       // exp_avg.lerp_(g, 1-b1)
+    vi = __fadd_rn(__fmul_rn(vi, a.b2), __fmul_rn(__fmul_rn(a.one_m_b2, gi), gi));      // mul_(b2).addcmul_(g,g,1-b2)
+    float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+    pi = __fadd_rn(pi, __fmul_rn(a.neg_step_size, __fdiv_rn(mi, denom)));                // addcdiv_(m, denom, -step)
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// entry points
+// ---------------------------------------------------------------------------------------------------------------
+static int check_buf(const mrl_rollout* b) {
+  if (!b) MRL_FAIL(MRL_EINVAL, "rollout buffer is NULL");
+  if (b->num_envs < 1 || b->horizon < 1) MRL_FAIL(MRL_EINVAL, "bad rollout shape N=%lld T=%d", (long long)b->num_envs, b->horizon);
+  if (b->num_envs * (int64_t)b->horizon >= (int64_t)1 << 31) MRL_FAIL(MRL_EINVAL, "N*T must be < 2^31");
+  return MRL_OK;
+}
+
+extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl_rms* obs_rms, const mrl_rms* value_rms,
+                              const float* obs, const float* noise, int32_t t, const mrl_rollout* buf,
+                              float* actions_clamped, float* last_values, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+  if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
+  if (!params || !obs || !workspace) MRL_FAIL(MRL_EINVAL, "NULL params/obs/workspace");
+  const int T = buf->horizon;
+  const int64_t N = buf->num_envs;
+  if (t < 0 || t > T) MRL_FAIL(MRL_EINVAL, "step %d outside 0..%d", t, T);
+  const bool boot = (t == T);
+  if (boot && !last_values) MRL_FAIL(MRL_EINVAL, "last_values required for the bootstrap step");
+  if (!boot && !noise) MRL_FAIL(MRL_EINVAL, "noise required");
+  if (obs_rms && obs_rms->size != net->obs_dim) MRL_FAIL(MRL_EINVAL, "obs_rms size %d != obs_dim %d", obs_rms->size, net->obs_dim);
+  Workspace W;
+  workspace_layout(net, N, &W);
+  if (workspace_bytes < W.total * 4) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)W.total * 4);
+  ParamLayout L;
+  param_layout(net, &L);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int O = net->obs_dim, A = net->act_dim;
+
+  if (!boot) {
+    int64_t total4 = N * (O / 4);
+    int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, obs, buf->obs, N, O / 4, (int64_t)T * (O / 4), (int64_t)t * (O / 4));
+  }
+  float *mean_f = nullptr, *std_f = nullptr;
+  float lo = -5.f, hi = 5.f;
+  if (obs_rms) {
+    mean_f = ws + W.small;
+    std_f = mean_f + O;
+    lo = obs_rms->clamp_lo; hi = obs_rms->clamp_hi;
+    hipLaunchKernelGGL(rms_to_f32_kernel, dim3((O + 63) / 64), dim3(64), 0, s, obs_rms->mean, obs_rms->var, obs_rms->eps, O, mean_f, std_f);
+  }
+  const int tw0 = boot ? 1 : 0, towers = boot ? 1 : 2;
+  launch_towers_fwd(net, L, W, ws, params, obs, N, mean_f, std_f, lo, hi, tw0, towers, s);
+
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  const int last = net->n_layers - 1, U = net->units[last];
+  for (int k = 0; k < towers; ++k) {
+    int tw = tw0 + k;
+    p.A[k] = ws + W.xhat[tw][last];
+    p.B[k] = params + L.Wh[tw];
+    p.pro0[k] = params + L.g[tw][last];
+    p.pro1[k] = params + L.be[tw][last];
+    p.bias[k] = params + L.bh[tw];
+    p.Nt[k] = (tw == 0) ? 2 * A : 1;
+    p.Kt[k] = U;
+  }
+  p.tw0 = tw0;
+  p.lda = U; p.ldb = U;
+  p.M = (int)N; p.N = 32; p.K = U;
+  p.a_pro = PRO_LNSILU;
+  fill_heads_common(net, &p.h);
+  p.h.noise = noise;
+  p.h.act_out = buf->actions; p.h.mu = buf->mu; p.h.sigma = buf->sigma;
+  p.h.out_rs = (int64_t)T * A; p.h.out_off = (int64_t)t * A;
+  p.h.act_clamped = actions_clamped;
+  p.h.neglogp_out = boot ? nullptr : buf->neglogp_tn + (int64_t)t * N;
+  p.h.value_out = boot ? last_values : buf->values_tn + (int64_t)t * N;
+  if (value_rms) {
+    p.h.vrms_mean = value_rms->mean; p.h.vrms_var = value_rms->var; p.h.vrms_eps = value_rms->eps;
+    p.clamp_lo = value_rms->clamp_lo; p.clamp_hi = value_rms->clamp_hi;
+  }
+  launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  MRL_CHECK_LAUNCH("mrl_policy_act");
+  return MRL_OK;
+}
+
+extern "C" int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,
+                                 const uint8_t* time_outs, float reward_scale, float gamma, void* stream) {
+  if (check_buf(buf)) return MRL_EINVAL;
+  if (t < 0 || t >= buf->horizon) MRL_FAIL(MRL_EINVAL, "step %d outside 0..%d", t, buf->horizon - 1);
+  if (!rewards || !dones) MRL_FAIL(MRL_EINVAL, "NULL rewards/dones");
+  const int64_t N = buf->num_envs;
+  hipLaunchKernelGGL(rollout_write_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                     buf->rewards_tn + (int64_t)t * N, buf->dones_tn + (int64_t)t * N, buf->values_tn + (int64_t)t * N, rewards,
+                     dones, time_outs, N, reward_scale, gamma);
+  MRL_CHECK_LAUNCH("mrl_rollout_write");
+  return MRL_OK;
+}
+
+extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, float gamma, float tau,
+                              const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+  if (check_buf(buf)) return MRL_EINVAL;
+  if (!last_values || !workspace) MRL_FAIL(MRL_EINVAL, "NULL last_values/workspace");
+  const int64_t N = buf->num_envs;
+  const int T = buf->horizon;
+  const int nblocks = (int)cdiv(N, 64);
+  const int64_t need = (int64_t)nblocks * 6 * 8 + 64;
+  if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  size_t smem = (size_t)4 * 64 * (T + 1) * sizeof(float);
+  if (smem > 64 * 1024) MRL_FAIL(MRL_EINVAL, "horizon %d too long for the scan tile", T);
+  hipStream_t s = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  float* stats = (float*)(part + (int64_t)nblocks * 6);
+  const float gamma_tau = (float)((double)gamma * (double)tau);
+  hipLaunchKernelGGL(gae_kernel, dim3(nblocks), dim3(64), smem, s, buf->rewards_tn, buf->values_tn, buf->dones_tn,
+                     buf->neglogp_tn, last_values, N, T, gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
+                     buf->neglogp, part);
+  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(256), 0, s, part, nblocks, (double)(N * T),
+                     value_rms ? value_rms->mean : nullptr, value_rms ? value_rms->var : nullptr,
+                     value_rms ? value_rms->count : nullptr, value_rms ? value_rms->eps : 0.f, stats);
+  const int64_t B = N * T;
+  hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, s, buf->advantages, buf->values,
+                     buf->returns, stats, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
+                     value_rms ? value_rms->clamp_hi : 0.f);
+  if (stats_out) hipMemcpyAsync(stats_out, stats, 8 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  MRL_CHECK_LAUNCH("mrl_gae_finish");
+  return MRL_OK;
+}
+
+extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int64_t group_rows, int32_t correction,
+                                 float* mean_out, float* var_out, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!x || !mean_out || !var_out || !workspace) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (cols < 1 || cols > 256) MRL_FAIL(MRL_EINVAL, "cols %d not in 1..256", cols);
+  if (rows < 1 || group_rows < 1 || rows % group_rows) MRL_FAIL(MRL_EINVAL, "rows %lld not a multiple of group_rows %lld", (long long)rows, (long long)group_rows);
+  const int64_t groups = rows / group_rows;
+  int64_t chunks = cdiv(1024, groups);
+  int64_t chunk_rows = cdiv(group_rows, chunks);
+  if (chunk_rows < 64) chunk_rows = 64;
+  chunks = cdiv(group_rows, chunk_rows);
+  if (groups > 65535) MRL_FAIL(MRL_EINVAL, "too many groups");
+  const int64_t need = groups * chunks * 2 * cols * 8;
+  if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  hipStream_t s = (hipStream_t)stream;
+  const int rowlanes = 256 / cols > 0 ? 256 / cols : 1;
+  size_t smem = (size_t)2 * rowlanes * cols * sizeof(double);
+  hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), smem, s, x, cols, group_rows,
+                     chunk_rows, (double*)workspace);
+  hipLaunchKernelGGL(moments_final_kernel, dim3((cols + 63) / 64, (unsigned)groups), dim3(64), 0, s, (const double*)workspace,
+                     (int)chunks, cols, (double)group_rows, correction, mean_out, var_out);
+  MRL_CHECK_LAUNCH("mrl_batch_moments");
+  return MRL_OK;
+}
+
+extern "C" int mrl_rms_merge(const mrl_rms* rms, const float* batch_mean, const float* batch_var, double batch_count,
+                             float* mean_f32_out, float* std_f32_out, void* stream) {
+  if (!rms || !rms->mean || !rms->var || !rms->count || !batch_mean || !batch_var) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (rms->size < 1 || rms->size > 1024) MRL_FAIL(MRL_EINVAL, "rms size %d not in 1..1024", rms->size);
+  hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rms->mean, rms->var, rms->count, batch_mean,
+                     batch_var, batch_count, rms->size, rms->eps, mean_f32_out, std_f32_out);
+  MRL_CHECK_LAUNCH("mrl_rms_merge");
+  return MRL_OK;
+}
+
+extern "C" int mrl_rms_normalize(const mrl_rms* rms, const float* x, float* y, int64_t rows, int32_t unnormalize, void* stream) {
+  if (!rms || !x || !y) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (rows < 0) MRL_FAIL(MRL_EINVAL, "rows < 0");
+  int64_t total = rows * rms->size;
+  if (total == 0) return MRL_OK;
+  hipLaunchKernelGGL(rms_normalize_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, rms->mean, rms->var,
+                     rms->eps, rms->clamp_lo, rms->clamp_hi, x, y, total, rms->size, unnormalize);
+  MRL_CHECK_LAUNCH("mrl_rms_normalize");
+  return MRL_OK;
+}
+
+extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
+                            int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
+                            float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+  if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
+  if (!params || !hp || !grads || !metrics_out || !workspace) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  const int64_t B = buf->num_envs * (int64_t)buf->horizon;
+  if (mb < 2 || row0 < 0 || row0 + mb > B) MRL_FAIL(MRL_EINVAL, "minibatch rows [%lld,%lld) outside the batch of %lld", (long long)row0, (long long)(row0 + mb), (long long)B);
+  if ((obs_mean == nullptr) != (obs_std == nullptr)) MRL_FAIL(MRL_EINVAL, "obs_mean and obs_std must both be given or both be NULL");
+  if (hp->bounds_type != 0 && hp->bounds_type != 1) MRL_FAIL(MRL_EINVAL, "bounds_type %d", hp->bounds_type);
+  Workspace W;
+  workspace_layout(net, mb, &W);
+  if (workspace_bytes < W.total * 4) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)W.total * 4);
+  ParamLayout L;
+  param_layout(net, &L);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int O = net->obs_dim, A = net->act_dim, nl = net->n_layers, last = nl - 1, U = net->units[last];
+  const float* x = buf->obs + row0 * O;
+
+  // ---- forward -------------------------------------------------------------------------------------------------
+  launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s);
+  double* metric_part = (double*)(ws + W.metric_part);
+  const int hblocks = (int)cdiv(mb, 128);
+  {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    for (int tw = 0; tw < 2; ++tw) {
+      p.A[tw] = ws + W.xhat[tw][last];
+      p.B[tw] = params + L.Wh[tw];
+      p.pro0[tw] = params + L.g[tw][last];
+      p.pro1[tw] = params + L.be[tw][last];
+      p.bias[tw] = params + L.bh[tw];
+      p.Nt[tw] = (tw == 0) ? 2 * A : 1;
+      p.Kt[tw] = U;
+      p.h.seeds[tw] = ws + W.seeds[tw];
+    }
+    p.lda = U; p.ldb = U;
+    p.M = (int)mb; p.N = 32; p.K = U;
+    p.a_pro = PRO_LNSILU;
+    fill_heads_common(net, &p.h);
+    p.h.actions = buf->actions + row0 * A;
+    p.h.mu = buf->mu + row0 * A;
+    p.h.sigma = buf->sigma + row0 * A;
+    p.h.old_neglogp = buf->neglogp + row0;
+    p.h.adv = buf->advantages + row0;
+    p.h.returns = buf->returns + row0;
+    p.h.value_preds = buf->values + row0;
+    p.h.metric_part = metric_part;
+    p.h.headb_part = ws + W.headb_part;
+    p.h.inv_mb = 1.0f / (float)mb;
+    p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
+    p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
+    launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN>(p, dim3(hblocks, 1, 2), s);
+  }
+  hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(64), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
+                     hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+
+  // ---- backward: dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) -----------------
+  for (int l = last; l >= 0; --l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const int u = net->units[l];
+    for (int tw = 0; tw < 2; ++tw) {
+      if (l == last) {
+        p.A[tw] = ws + W.seeds[tw];
+        p.B[tw] = params + L.Wh[tw];
+        p.Kt[tw] = (tw == 0) ? 2 * A : 1;
+      } else {
+        p.A[tw] = ws + W.dz[tw][l + 1];
+        p.B[tw] = params + L.W[tw][l + 1];
+        p.Kt[tw] = net->units[l + 1];
+      }
+      p.Nt[tw] = u;
+      p.out[tw] = ws + W.dz[tw][l];
+      p.xhat[tw] = ws + W.xhat[tw][l];
+      p.rstd[tw] = ws + W.rstd[tw][l];
+      p.gamma[tw] = params + L.g[tw][l];
+      p.beta[tw] = params + L.be[tw][l];
+      p.colpart[tw] = ws + W.colpart[tw][l];
+    }
+    const int kdim = (l == last) ? 32 : net->units[l + 1];
+    p.lda = kdim; p.ldb = u; p.ldo = u;
+    p.M = (int)mb; p.N = u; p.K = kdim;
+    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, p, 2, s);
+  }
+
+  // ---- backward: wgrad partial slabs -----------------------------------------------------------------------------
+  for (int l = last + 1; l >= 0; --l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const bool head = (l == last + 1);
+    const int gm = head ? 32 : net->units[l];
+    const int gn = head ? U : L.in_dim[l];
+    const WgradPlan& wp = head ? W.wph : W.wp[l];
+    for (int tw = 0; tw < 2; ++tw) {
+      p.A[tw] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
+      p.B[tw] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
+      p.pro0[tw] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
+      p.pro1[tw] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
+      p.out[tw] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
+      p.Nt[tw] = gn; p.Kt[tw] = (int)mb;
+    }
+    p.lda = gm; p.ldb = gn; p.ldo = gn;
+    p.M = gm; p.N = gn; p.K = (int)mb;
+    p.b_pro = (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU;
+    p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
+    p.ksplit = wp.ksplit; p.n_tiles = wp.tiles_n;
+    launch_wgrad(p, wp, 2, s);
+  }
+
+  // ---- reduce partial slabs into the flat gradient -----------------------------------------------------------------
+  ReduceTable tab;
+  tab.n = 0;
+  auto add = [&](const float* src, int64_t off, int64_t count, int64_t stride, int nslabs) {
+    ReduceDesc& d = tab.d[tab.n++];
+    d.src = src; d.dst = grads + off; d.count = count; d.stride = stride; d.nslabs = nslabs;
+  };
+  int64_t maxcount = 0;
+  for (int tw = 0; tw < 2; ++tw) {
+    for (int l = 0; l < nl; ++l) {
+      const int u = net->units[l];
+      add(ws + W.slab[tw][l], L.W[tw][l], (int64_t)u * L.in_dim[l], (int64_t)u * L.in_dim[l], W.wp[l].nsplit);
+      const float* cp = ws + W.colpart[tw][l];
+      add(cp + 2 * u, L.b[tw][l], u, 3 * u, W.rowblocks[l]);
+      add(cp, L.g[tw][l], u, 3 * u, W.rowblocks[l]);
+      add(cp + u, L.be[tw][l], u, 3 * u, W.rowblocks[l]);
+      if ((int64_t)u * L.in_dim[l] > maxcount) maxcount = (int64_t)u * L.in_dim[l];
+    }
+    const int hn = (tw == 0) ? 2 * A : 1;
+    add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
+    add(ws + W.headb_part + tw * 32, L.bh[tw], hn, 64, hblocks);
+  }
+  {
+    int gx = (int)cdiv(maxcount, 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
+  }
+  MRL_CHECK_LAUNCH("mrl_ppo_grad");
+  return MRL_OK;
+}
+
+extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
+                             float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (count < 1 || step < 1) MRL_FAIL(MRL_EINVAL, "count %lld / step %lld must be >= 1", (long long)count, (long long)step);
+  hipStream_t s = (hipStream_t)stream;
+  AdamArgs a;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  a.lr_wd_mul = (float)(1.0 - lr * weight_decay);
+  a.l2 = adamw ? 0.f : (float)weight_decay;
+  a.one_m_b1 = (float)(1.0 - beta1);
+  a.b2 = (float)beta2;
+  a.one_m_b2 = (float)(1.0 - beta2);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = (float)eps;
+  a.neg_step_size = (float)(-(lr / bc1));
+  a.max_norm = max_norm;
+  a.grad_scale = grad_scale;
+  a.adamw = adamw;
+  a.nparts = 0;
+  if (max_norm > 0.f) {
+    int64_t np = cdiv(count, 2048);
+    a.nparts = (int)(np > 256 ? 256 : np);
+    hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(a.nparts), dim3(256), 0, s, grads, count, grad_scale, (double*)scratch);
+  }
+  int64_t blocks = cdiv(count, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count,
+                     (const double*)scratch, a, gnorm_out);
+  MRL_CHECK_LAUNCH("mrl_adam_step");
+  return MRL_OK;
+}

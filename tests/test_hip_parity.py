@@ -1,0 +1,446 @@
+"""GPU parity: the HIP path (through the C ABI / the host classes that call it) against the CPU oracle and the
+golden vectors of the reference.  Integer / index results must be bit-exact; fp32 results use the tolerance
+written at each comparison (the GEMMs sum in a different order than torch's CPU kernels).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+@pytest.fixture(scope='module')
+def hip():
+    _need_gpu()
+    from mineral_amd import _hip
+    _hip.lib()
+    return _hip
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def cpu(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu()
+
+
+def assert_close(a, b, rtol, atol, what=''):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+NETS = {
+    'mid': dict(obs=64, act=12, units=[128, 64, 32]),
+    'full': dict(obs=64, act=12, units=[512, 256, 128]),
+    'wide2': dict(obs=20, act=3, units=[256, 32]),
+}
+
+
+def oracle_cfg(spec, dist='dreamerv3_normal'):
+    return O.NetConfig(spec['obs'], spec['act'], spec['units'], 'LayerNorm', 'SiLU', False, dist, 0.1, 1.0)
+
+
+def oracle_params(spec, seed):
+    shapes = synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], True, True, False)
+    return synth.make_params(shapes, seed)
+
+
+def make_model(spec, params, dist='dreamerv3_normal'):
+    from mineral_amd.agents.ppo.models import ActorCritic
+    m = ActorCritic({'obs': (spec['obs'],)}, spec['act'], mlp_kwargs=dict(units=spec['units'], norm_type='LayerNorm', act_type='SiLU'),
+                    fixed_sigma=False, actor_dist_kwargs=dict(dist_type=dist, minstd=0.1, maxstd=1.0), device=DEV)
+    m.load_state_dict(params)
+    return m
+
+
+def make_buffer(spec, N, T, mb=None):
+    from mineral_amd.agents.ppo.experience import ExperienceBuffer
+    return ExperienceBuffer(N, T, N * T, mb or N * T, {'obs': (spec['obs'],)}, spec['act'], DEV)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('T,N', [(4, 8), (32, 64), (32, 1000), (7, 333), (1, 5)])
+def test_gae_flatten_advnorm_valuenorm(hip, golden, T, N):
+    from mineral_amd.common.normalizers import RunningMeanStd
+    spec = NETS['mid']
+    buf = make_buffer(spec, N, T)
+    rewards, values = synth.gaussianish((T, N, 1), 11), synth.gaussianish((T, N, 1), 12)
+    dones = (synth.lcg_t((T, N), 14) > 0.4).to(torch.uint8)
+    neglogp = synth.gaussianish((T, N), 13)
+    last_values = synth.gaussianish((N, 1), 18)
+    s = buf.storage_dict
+    s['rewards'].copy_(rewards); s['values'].copy_(values); s['dones'].copy_(dones); s['neglogp'].copy_(neglogp)
+    vr = RunningMeanStd((1,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    buf.compute_return(dev(last_values), 0.99, 0.95, vr)
+    d = buf.prepare_training()
+    # oracle
+    ret, _ = O.gae_returns(rewards, values, dones, last_values, 0.99, 0.95)
+    fr, fv = O.flatten_env_major(ret), O.flatten_env_major(values)
+    adv = O.normalize_advantages(fr, fv) if N * T > 1 else None
+    st = O.rms_init((1,))
+    st = O.rms_update(st, fv); nv = O.rms_normalize(st, fv)
+    st = O.rms_update(st, fr); nr = O.rms_normalize(st, fr)
+    # the un-normalised GAE returns are bit-exact: check through the inverse of the value normalisation is not
+    # possible, so run once more without value_rms
+    buf2 = make_buffer(spec, N, T)
+    for k in ('rewards', 'values', 'dones', 'neglogp'):
+        buf2.storage_dict[k].copy_(s[k])
+    buf2.compute_return(dev(last_values), 0.99, 0.95, None)
+    d2 = buf2.prepare_training()
+    assert torch.equal(cpu(d2['returns']), fr), 'GAE returns must be bit-exact'
+    assert torch.equal(cpu(d2['values']), fv)
+    assert torch.equal(cpu(d2['neglogp']), O.flatten_env_major(neglogp)), 'flat index map n*T+t'
+    assert torch.equal(cpu(d2['dones']), O.flatten_env_major(dones))
+    if adv is not None and N * T > 2:
+        assert_close(cpu(d2['advantages']), adv, 2e-6, 2e-6, 'advantages')
+        assert_close(cpu(d['advantages']), adv, 2e-6, 2e-6, 'advantages')
+        assert_close(cpu(d['values']), nv, 2e-6, 2e-6, 'normalised values')
+        assert_close(cpu(d['returns']), nr, 2e-6, 2e-6, 'normalised returns')
+        assert_close(cpu(vr.running_mean), st['running_mean'], 1e-6, 1e-9)
+        assert_close(cpu(vr.running_var), st['running_var'], 1e-6, 1e-9)
+        assert cpu(vr.running_count).item() == st['running_count'].item()
+    if (T, N) == (32, 64):
+        g = golden('g1_gae_mid')
+        assert np.array_equal(cpu(d2['returns']).numpy(), g['flat_returns'])
+        assert_close(cpu(d2['advantages']), g['advantages'], 2e-6, 2e-6)
+
+
+def test_running_mean_std_golden(hip, golden):
+    from mineral_amd.common.normalizers import RunningMeanStd
+    g = golden('g3_rms_ppo')
+    rms = RunningMeanStd((6,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    for i in range(5):
+        x = synth.gaussianish((37 + 11 * i, 6), 100 + i) * (1.0 + i) + 0.3 * i
+        rms.update(dev(x))
+        assert_close(cpu(rms.running_mean), g[f'mean{i}'], 1e-6, 1e-8, f'mean{i}')
+        assert_close(cpu(rms.running_var), g[f'var{i}'], 2e-6, 1e-8, f'var{i}')
+        assert cpu(rms.running_count).item() == float(g[f'count{i}'])
+        assert_close(cpu(rms.normalize(dev(x * 3))), g[f'norm{i}'], 2e-6, 2e-6, f'norm{i}')
+        assert_close(cpu(rms.unnormalize(dev(x * 3))), g[f'unnorm{i}'], 2e-6, 2e-6, f'unnorm{i}')
+
+
+def test_batch_moments_groups(hip):
+    x = synth.gaussianish((4096, 64), 5) * 3 + 1.5
+    L = hip.lib()
+    mean = torch.empty(8, 64, device=DEV); var = torch.empty(8, 64, device=DEV)
+    ws = torch.empty(8 * 1024 * 2 * 64 * 8, dtype=torch.uint8, device=DEV)
+    hip.check(L.mrl_batch_moments(hip.ptr(dev(x)), 4096, 64, 512, 1, hip.ptr(mean), hip.ptr(var), hip.ptr(ws), ws.numel(), None), 'm')
+    xr = x.view(8, 512, 64)
+    assert_close(cpu(mean), xr.mean(1), 1e-6, 1e-7)
+    assert_close(cpu(var), xr.var(1, correction=1), 2e-6, 1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('net,N,dist', [('mid', 64, 'dreamerv3_normal'), ('full', 16, 'dreamerv3_normal'), ('full', 300, 'normal'),
+                                       ('wide2', 129, 'dreamerv3_normal')])
+def test_policy_act(hip, golden, net, N, dist):
+    from mineral_amd.common.normalizers import RunningMeanStd
+    spec = NETS[net]
+    T = 3
+    params = oracle_params(spec, 3)
+    cfg = oracle_cfg(spec, dist)
+    model = make_model(spec, params, dist)
+    buf = make_buffer(spec, N, T)
+    obs = synth.gaussianish((N, spec['obs']), 41)
+    noise = synth.gaussianish((N, spec['act']), 43)
+    obs_rms = RunningMeanStd((spec['obs'],), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    value_rms = RunningMeanStd((1,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    xs = synth.gaussianish((50, spec['obs']), 77) * 1.5 + 0.2
+    vs = synth.gaussianish((50, 1), 78) * 2.0 + 0.5
+    obs_rms.update(dev(xs)); value_rms.update(dev(vs))
+    o_obs = O.rms_update(O.rms_init((spec['obs'],)), xs)
+    o_val = O.rms_update(O.rms_init((1,)), vs)
+    L = hip.lib()
+    ws = torch.empty(int(L.mrl_workspace_bytes(model.net, N)), dtype=torch.uint8, device=DEV)
+    clamped = torch.empty(N, spec['act'], device=DEV)
+    t = 1
+    hip.check(L.mrl_policy_act(model.net, hip.ptr(model.flat), obs_rms.c_struct(), value_rms.c_struct(), hip.ptr(dev(obs)),
+                               hip.ptr(dev(noise)), t, buf.c, hip.ptr(clamped), None, hip.ptr(ws), ws.numel(), None), 'act')
+    ref = O.model_act(params, O.rms_normalize(o_obs, obs), noise, cfg)
+    ref_v = O.rms_unnormalize(o_val, ref['values'])
+    s = buf.storage_dict
+    tol = dict(rtol=2e-5, atol=2e-5)
+    assert torch.equal(cpu(s['obses']['obs'][:, t]), obs)
+    assert_close(cpu(s['mu'][:, t]), ref['mu'], **tol, what='mu')
+    assert_close(cpu(s['sigma'][:, t]), ref['sigma'], **tol, what='sigma')
+    assert_close(cpu(s['actions'][:, t]), ref['actions'], **tol, what='actions')
+    assert_close(cpu(clamped), ref['actions'].clamp(-1, 1), **tol, what='clamped')
+    assert_close(cpu(s['neglogp'][t]), ref['neglogp'], rtol=2e-5, atol=1e-4, what='neglogp')
+    assert_close(cpu(s['values'][t]), ref_v, **tol, what='values')
+    assert float(s['mu'][:, 0].abs().sum()) == 0.0 and float(s['mu'][:, 2].abs().sum()) == 0.0, 'only row t is written'
+    # bootstrap forward: values only
+    last = torch.empty(N, device=DEV)
+    hip.check(L.mrl_policy_act(model.net, hip.ptr(model.flat), obs_rms.c_struct(), value_rms.c_struct(), hip.ptr(dev(obs)),
+                               None, T, buf.c, None, hip.ptr(last), hip.ptr(ws), ws.numel(), None), 'act boot')
+    assert_close(cpu(last), ref_v.squeeze(1), **tol, what='last_values')
+    if net == 'full' and N == 16 and dist == 'dreamerv3_normal':
+        # the reference's own outputs for this network (no normalisers): golden g4
+        g = golden('g4_model_full_dv3')
+        ident_o = RunningMeanStd((spec['obs'],), eps=0.0, with_clamp=True, initial_count=1, device=DEV)
+        buf4 = make_buffer(spec, 16, 1)
+        hip.check(L.mrl_policy_act(model.net, hip.ptr(model.flat), None, None, hip.ptr(dev(obs)), hip.ptr(dev(noise)), 0, buf4.c,
+                                   hip.ptr(clamped), None, hip.ptr(ws), ws.numel(), None), 'act g4')
+        s4 = buf4.storage_dict
+        assert_close(cpu(s4['mu'][:, 0]), g['act_mu'], **tol)
+        assert_close(cpu(s4['sigma'][:, 0]), g['act_sigma'], **tol)
+        assert_close(cpu(s4['actions'][:, 0]), g['act_actions'], **tol)
+        assert_close(cpu(s4['neglogp'][0]), g['act_neglogp'], rtol=2e-5, atol=1e-4)
+        assert_close(cpu(s4['values'][0]), g['act_values'], **tol)
+        del ident_o
+
+
+def _fill_training_buffer(spec, buf, N, T, seed=0):
+    B = N * T
+    A = spec['act']
+    data = {
+        'obs': synth.gaussianish((B, spec['obs']), 200 + seed) * 1.3 + 0.1,
+        'actions': synth.gaussianish((B, A), 201 + seed) * 0.7,
+        'mu': torch.tanh(synth.gaussianish((B, A), 202 + seed) * 0.5),
+        'sigma': synth.lcg_t((B, A), 203 + seed) * 0.6 + 0.5,
+        'neglogp': synth.gaussianish((B,), 204 + seed) * 0.5 + 11.0,
+        'advantages': synth.gaussianish((B,), 205 + seed),
+        'returns': synth.gaussianish((B, 1), 206 + seed),
+        'values': synth.gaussianish((B, 1), 207 + seed),
+    }
+    s = buf.storage_dict
+    s['obses']['obs'].view(B, -1).copy_(data['obs'])
+    s['actions'].view(B, A).copy_(data['actions'])
+    s['mu'].view(B, A).copy_(data['mu'])
+    s['sigma'].view(B, A).copy_(data['sigma'])
+    buf._flat['neglogp'].copy_(data['neglogp'])
+    buf._flat['advantages'].copy_(data['advantages'])
+    buf._flat['returns'].copy_(data['returns'].squeeze(1))
+    buf._flat['values'].copy_(data['values'].squeeze(1))
+    return data
+
+
+@pytest.mark.parametrize('net,N,T,mb,dist,clipv,btype', [
+    ('mid', 64, 8, 128, 'dreamerv3_normal', 0, 'bound'),
+    ('mid', 50, 4, 100, 'normal', 1, 'reg'),
+    ('full', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
+    ('wide2', 37, 8, 148, 'dreamerv3_normal', 0, 'bound'),
+    ('full', 32, 32, 1024, 'dreamerv3_normal', 0, 'bound'),
+])
+def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
+    spec = NETS[net]
+    params = oracle_params(spec, 9)
+    cfg = oracle_cfg(spec, dist)
+    model = make_model(spec, params, dist)
+    buf = make_buffer(spec, N, T, mb)
+    data = _fill_training_buffer(spec, buf, N, T)
+    hp = O.PPOHParams(horizon_len=T, minibatch_size=mb, clip_value_loss=bool(clipv), bounds_type=btype, entropy_coef=0.01,
+                      bounds_loss_coef=0.05 if dist == 'normal' else 1e-4)
+    chp = hip.PpoHp(hp.e_clip, hp.critic_coef, hp.entropy_coef, hp.bounds_loss_coef, 0 if btype == 'bound' else 1, clipv)
+    L = hip.lib()
+    ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
+    grads = torch.full((model.param_count,), float('nan'), device=DEV)
+    metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
+    # normaliser vectors as the merge kernel emits them
+    o_rms = O.rms_update(O.rms_init((spec['obs'],)), data['obs'][:mb])
+    mean_f = dev(o_rms['running_mean'].float())
+    std_f = dev(torch.sqrt(o_rms['running_var'].float() + 1e-5))
+    row0 = (N * T // mb - 1) * mb     # the last minibatch
+    sl = slice(row0, row0 + mb)
+    hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, row0, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0,
+                             hip.ptr(grads), hip.ptr(metrics), hip.ptr(ws), ws.numel(), None), 'grad')
+    # oracle on the same minibatch
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    mbd = {k: v[sl] for k, v in data.items()}
+    out = O.model_forward(leaves, O.rms_normalize(o_rms, mbd['obs']), mbd['actions'], cfg)
+    loss, diag = O.total_loss(out, mbd, hp)
+    g = torch.autograd.grad(loss, list(leaves.values()))
+    g = dict(zip(leaves.keys(), g))
+    kl = O.policy_kl(out['mu'].detach(), out['sigma'].detach(), mbd['mu'], mbd['sigma'])
+    gv = model.views_of(grads)
+    torch.cuda.synchronize()
+    assert not torch.isnan(grads).any(), 'every gradient element must be written'
+    for name, ref in g.items():
+        got = cpu(gv[name])
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((got - ref).abs().max())
+        assert err <= 3e-4 * scale + 1e-9, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
+    m = cpu(metrics)
+    names = dict(zip(hip.METRIC_NAMES, m.tolist()))
+    assert_close(names['loss/actor'], float(diag['loss/actor']), 2e-4, 1e-6, 'a_loss')
+    assert_close(names['loss/critic'], float(diag['loss/critic']), 2e-4, 1e-6, 'c_loss')
+    assert_close(names['loss/entropy'], float(diag['loss/entropy']), 2e-5, 1e-6, 'entropy')
+    assert_close(names['loss/bounds'], float(diag['loss/bounds']), 2e-4, 1e-7, 'b_loss')
+    assert_close(names['loss/total'], float(diag['loss/total']), 2e-4, 1e-6, 'total')
+    assert_close(names['clip_frac'], float(diag['clip_frac']), 0, 1.5 / mb, 'clip_frac')
+    assert_close(names['explained_var'], float(diag['explained_var']), 2e-4, 1e-5, 'explained_var')
+    assert_close(names['kl'], float(kl), 2e-4, 1e-6, 'kl')
+    # mu / sigma write-back of exactly this minibatch's rows
+    A = spec['act']
+    mu_after = cpu(buf.storage_dict['mu'].view(-1, A))
+    assert_close(mu_after[sl], out['mu'].detach(), 2e-5, 2e-5, 'mu write-back')
+    assert torch.equal(mu_after[:row0], data['mu'][:row0]), 'rows outside the minibatch are untouched'
+    assert_close(cpu(buf.storage_dict['sigma'].view(-1, A))[sl], out['sigma'].detach(), 2e-5, 2e-5, 'sigma write-back')
+
+    # ---- clip + Adam / AdamW on the flat vectors against the oracle's per-tensor step --------------------------------
+    for optim in ('AdamW', 'Adam'):
+        p_ref = {k: v.clone() for k, v in params.items()}
+        st = O.adam_state_init(p_ref)
+        model.load_state_dict(params)
+        m1 = torch.zeros_like(model.flat); m2 = torch.zeros_like(model.flat)
+        gn = torch.zeros(1, device=DEV)
+        scratch = torch.empty(4096, dtype=torch.uint8, device=DEV)
+        gh = {k: cpu(gv[k]).clone() for k in g}
+        for step in (1, 2, 3):
+            clipped, total = O.clip_grad_norm(list(gh.values()), 0.5)
+            O.adam_step(p_ref, dict(zip(gh.keys(), clipped)), st, 5e-4, optim, eps=1e-5)
+            hip.check(L.mrl_adam_step(hip.ptr(model.flat), hip.ptr(grads), hip.ptr(m1), hip.ptr(m2), model.param_count, 5e-4, 0.9,
+                                      0.999, 1e-5, 0.01 if optim == 'AdamW' else 0.0, 1 if optim == 'AdamW' else 0, step, 0.5, 1.0,
+                                      hip.ptr(gn), hip.ptr(scratch), None), 'adam')
+        assert_close(cpu(gn)[0], float(total), 1e-5, 1e-9, 'grad norm')
+        for name, ref in p_ref.items():
+            assert_close(cpu(model._views[name]), ref, 1e-5, 1e-7, f'{optim} {name}')
+        mv = model.views_of(m1)
+        for name in p_ref:
+            assert_close(cpu(mv[name]), st['exp_avg'][name], 1e-5, 1e-10, f'{optim} exp_avg {name}')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, logdir):
+    from mineral_amd.config import Config
+    ppo = dict(multi_gpu=False, num_actors=N, reward_shaper=dict(fn='scale', scale=0.5), max_agent_steps=epochs * N * T,
+               horizon_len=T, minibatch_size=mb, normalize_value=True, value_bootstrap=True, clip_value_loss=False,
+               normalize_advantage=True, gamma=0.99, tau=0.95, entropy_coef=0.0, e_clip=0.2, use_smooth_clamp=False,
+               critic_coef=4, bounds_loss_coef=0.0001, bounds_type='bound', mini_epochs=mini_epochs, optim_type=optim,
+               optim_kwargs=dict(lr=5e-4, eps=1e-5), lr_schedule='kl', kl_threshold=0.008, max_grad_norm=0.5, truncate_grads=True)
+    return Config.wrap(dict(
+        rl_device=DEV, sim_device=DEV, multi_gpu=False, env_render=False, run='train', seed=42,
+        task=dict(name='Golden', env=dict(numEnvs=N), env_autoresets=True),
+        agent=dict(algo='PPO', print_every=-1, ckpt_every=-1, tracker_len=100, metrics_kwargs={},
+                   network=dict(normalize_input=True, actor_critic='ActorCritic',
+                                actor_critic_kwargs=dict(separate_value_mlp=True,
+                                                         mlp_kwargs=dict(units=spec['units'], norm_type='LayerNorm', act_type='SiLU'),
+                                                         fixed_sigma=False,
+                                                         actor_dist_kwargs=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0))),
+                   ppo=ppo)))
+
+
+def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path):
+    """PPO.train() of the product on the deterministic env against what the REFERENCE produced (fixture g8 mid)."""
+    from mineral_amd.agents import PPO
+    g = golden('g8_train_mid_dv3_adamw')
+    spec = NETS['mid']
+    N, T, mb, mini_epochs, epochs = 64, 8, 128, 2, 2
+    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
+    agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    agent.model.load_state_dict(oracle_params(spec, 5))
+    agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
+    agent.save = lambda *a, **k: None
+    agent._checkpoint_save = lambda *a, **k: None
+    seen = {}
+    orig = agent.train_epoch
+
+    def spy():
+        e = agent.epoch
+        if e == 0:
+            d = agent.storage.data_dict
+            seen['pre'] = {k: cpu(d[k]).clone() for k in ('values', 'returns', 'advantages', 'neglogp', 'actions', 'mu', 'sigma',
+                                                         'rewards', 'dones')}
+            seen['pre']['obs'] = cpu(d['obses']['obs']).clone()
+        res = orig()
+        seen[f'kl{e}'] = cpu(res['avg_kl']).clone()
+        seen[f'lr{e}'] = agent.last_lr
+        seen[f'mu{e}'] = cpu(agent.storage.data_dict['mu']).clone()
+        seen[f'obs_rms{e}'] = {k: cpu(v).clone() for k, v in agent.obs_rms['obs'].state_dict().items()}
+        seen[f'val_rms{e}'] = {k: cpu(v).clone() for k, v in agent.value_rms.state_dict().items()}
+        for k in ('loss/total', 'loss/actor', 'loss/critic', 'clip_frac', 'explained_var', 'grad_norm/all'):
+            seen[f'{k}{e}'] = cpu(res[k]).clone()
+        return res
+
+    agent.train_epoch = spy
+    agent.train()
+    tol = dict(rtol=1e-4, atol=2e-5)
+    pre = seen['pre']
+    assert np.array_equal(pre['dones'].numpy(), g['e0_pre_dones'])
+    for k in ('obs', 'actions', 'mu', 'sigma', 'rewards', 'values', 'returns', 'advantages'):
+        assert_close(pre[k], g[f'e0_pre_{k}'], **tol, what=f'rollout {k}')
+    assert_close(pre['neglogp'], g['e0_pre_neglogp'], rtol=1e-4, atol=2e-4, what='rollout neglogp')
+    for e in range(epochs):
+        assert_close(seen[f'kl{e}'], g[f'e{e}_kl'], rtol=5e-3, atol=2e-6, what=f'avg_kl epoch {e}')
+        assert seen[f'lr{e}'] == float(g[f'e{e}_last_lr']), 'KL-adaptive learning rate path'
+        assert_close(seen[f'mu{e}'], g[f'e{e}_data_mu'], **tol, what='mu write-back')
+        assert_close(seen[f'obs_rms{e}']['running_mean'], g[f'e{e}_obs_rms_mean'], 1e-6, 1e-8)
+        assert_close(seen[f'obs_rms{e}']['running_var'], g[f'e{e}_obs_rms_var'], 1e-5, 1e-8)
+        assert seen[f'obs_rms{e}']['running_count'].item() == float(g[f'e{e}_obs_rms_count'])
+        assert_close(seen[f'val_rms{e}']['running_mean'], g[f'e{e}_value_rms_mean'], 1e-4, 1e-6)
+        for k in ('loss/total', 'loss/actor', 'loss/critic', 'explained_var', 'grad_norm/all'):
+            assert_close(seen[f'{k}{e}'], g[f'e{e}_{k.replace("/", "_")}'], rtol=2e-3, atol=2e-5, what=f'{k} epoch {e}')
+    last = epochs - 1
+    for n, p in agent.model.named_parameters():
+        assert_close(cpu(p), g[f'e{last}_p_{n}'], rtol=2e-3, atol=2e-5, what=f'final {n}')
+    assert agent.agent_steps == int(g['agent_steps'])
+
+
+def test_full_size_properties(hip):
+    """BASELINE-size shapes (N=65536 envs, T=32, minibatch 32768) through size-independent properties."""
+    from mineral_amd.common.normalizers import RunningMeanStd
+    spec = NETS['full']
+    N, T, mb = 65536, 32, 32768
+    buf = make_buffer(spec, N, T, mb)
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    s = buf.storage_dict
+    s['rewards'].normal_(generator=g); s['values'].normal_(generator=g)
+    s['dones'].copy_((torch.rand(T, N, device=DEV, generator=g) < 0.01).to(torch.uint8))
+    s['neglogp'].copy_(torch.arange(T * N, device=DEV, dtype=torch.float32).view(T, N) % 4096)
+    last = torch.randn(N, device=DEV, generator=g)
+    vr = RunningMeanStd((1,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    buf.compute_return(last, 0.99, 0.95, vr)
+    d = buf.prepare_training()
+    torch.cuda.synchronize()
+    # index map: neglogp payload is a function of (t, n)
+    idx = torch.arange(N * T, device=DEV)
+    n, t = idx // T, idx % T
+    assert torch.equal(d['neglogp'], ((t * N + n) % 4096).float())
+    adv = d['advantages'].double()
+    assert abs(adv.mean().item()) < 1e-5 and abs(adv.std().item() - 1.0) < 1e-5
+    assert vr.running_count.item() == 1 + 2 * N * T
+    # terminal rows: with done[t]=1 the return of step t is reward + 0 (no bootstrap), checked on the raw recursion
+    buf2 = make_buffer(spec, N, T, mb)
+    for k in ('rewards', 'values', 'dones', 'neglogp'):
+        buf2.storage_dict[k].copy_(s[k])
+    buf2.compute_return(last, 0.99, 0.95, None)
+    d2 = buf2.prepare_training()
+    ret_tn = d2['returns'].view(N, T).t()
+    done = s['dones'].bool()
+    assert torch.equal(ret_tn[done], s['rewards'].squeeze(-1)[done]), 'terminal steps return exactly their reward'
+    # full-size minibatch gradient: finite everywhere and bit-reproducible (fixed-order reductions, no atomics)
+    params = oracle_params(spec, 4)
+    model = make_model(spec, params)
+    s['obses']['obs'].normal_(generator=g)
+    s['actions'].normal_(generator=g).mul_(0.5)
+    L = hip.lib()
+    ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
+    chp = hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0)
+    mean_f = torch.zeros(64, device=DEV); std_f = torch.ones(64, device=DEV)
+    metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
+    outs = []
+    for rep in range(2):
+        s['mu'].zero_(); s['sigma'].fill_(0.6)
+        buf._flat['neglogp'].fill_(12.0)
+        gr = torch.full_like(model.flat, float('nan'))
+        hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, mb, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0,
+                                 hip.ptr(gr), hip.ptr(metrics), hip.ptr(ws), ws.numel(), None), 'grad')
+        outs.append(gr)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), 'gradients are bit-reproducible'
+    assert torch.isfinite(metrics).all()
