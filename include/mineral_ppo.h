@@ -115,14 +115,14 @@ int mrl_policy_act(const mrl_net* net, const float* params, const mrl_rms* obs_r
 /* Reward shaping + time-out bootstrap + done flags of one step (ppo.py:153-163, reward_shaper.py:10-15):
  * rewards_tn[t] = r*scale (+ gamma*values_tn[t]*time_outs), dones_tn[t] = dones.  time_outs may be NULL. */
 int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,
-                      const uint8_t* time_outs, float reward_scale, float gamma, void* stream);
+                      const uint8_t* time_outs, double reward_scale, double gamma, void* stream);
 
 /* ExperienceBuffer.compute_return + prepare_training + the value-normalisation stage
  * (experience.py:96-121, ppo.py:172-183): GAE(lambda) reverse scan, env-major flattening of the per-sample
  * scalars, whole-batch advantage normalisation (unbiased std, +1e-8), then value_rms.update(values) /
  * normalize / update(returns) / normalize.  value_rms may be NULL (normalize_value off).
  * stats_out (optional, 8 floats): adv mean, adv std, value mean/std after 1st update, after 2nd update. */
-int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, float gamma, float tau,
+int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
                    const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
                    void* stream);
 

@@ -230,8 +230,22 @@ static void fill_heads_common(const mrl_net* net, HeadsP* h) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// streaming kernels
+// streaming kernels.  Floating-point contraction is switched off for them: each mul / add rounds once, like the
+// element-wise torch ops they restate, so GAE, reward shaping and the Adam update agree with the reference bit for
+// bit (hipcc would otherwise fuse a*b+c into one fma).
 // ---------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+// single-rounding helpers compiled without contraction (the __f*_rn wrappers of the HIP headers still fuse)
+static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+static __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+
+__global__ void fill_zero_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 __global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int cols4,
                                  int64_t dst_row_stride4, int64_t dst_off4) {
   // src [rows][cols] contiguous -> dst[row*stride + off + c]; all in float4 units
@@ -258,10 +272,10 @@ __global__ void rollout_write_kernel(float* __restrict__ rewards_t, uint8_t* __r
                                      float scale, float gamma) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = __fmul_rn(r[i], scale);                                   // reward_shaper.py:10-12
+  float s = mul_rn(r[i], scale);                                   // reward_shaper.py:10-12
   if (time_outs) {                                                    // ppo.py:159-162
-    float b = __fmul_rn(__fmul_rn(gamma, values_t[i]), time_outs[i] ? 1.0f : 0.0f);
-    s = __fadd_rn(s, b);
+    float b = mul_rn(mul_rn(gamma, values_t[i]), time_outs[i] ? 1.0f : 0.0f);
+    s = add_rn(s, b);
   }
   rewards_t[i] = s;
   dones_t[i] = dones[i] ? 1 : 0;
@@ -293,12 +307,12 @@ __global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ rewar
       float v = values[i];
       float nnt = 1.0f - (float)dones[i];
       // delta = r + gamma*next_values*nnt - v ; adv = delta + (gamma*tau)*nnt*last   (unfused, as torch evaluates it)
-      float delta = __fsub_rn(__fadd_rn(rewards[i], __fmul_rn(__fmul_rn(gamma, next_v), nnt)), v);
-      last = __fadd_rn(delta, __fmul_rn(__fmul_rn(gamma_tau, nnt), last));
-      float ret = __fadd_rn(last, v);
+      float delta = sub_rn(add_rn(rewards[i], mul_rn(mul_rn(gamma, next_v), nnt)), v);
+      last = add_rn(delta, mul_rn(mul_rn(gamma_tau, nnt), last));
+      float ret = add_rn(last, v);
       s_ret[lane * S + t] = ret;
       s_val[lane * S + t] = v;
-      float adv = __fsub_rn(ret, v);      // experience.py:119: advantages = returns - values
+      float adv = sub_rn(ret, v);      // experience.py:119: advantages = returns - values
       s_adv[lane * S + t] = adv;
       s_nlp[lane * S + t] = neglogp_tn[i];
       sa += adv; sa2 += (double)adv * adv;
@@ -375,10 +389,10 @@ __global__ void gae_normalize_kernel(float* __restrict__ adv, float* __restrict_
                                      const float* __restrict__ stats, int64_t n, int norm_value, float lo, float hi) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  adv[i] = __fdiv_rn(__fsub_rn(adv[i], stats[0]), __fadd_rn(stats[1], 1e-8f));   // experience.py:120
+  adv[i] = div_rn(sub_rn(adv[i], stats[0]), add_rn(stats[1], 1e-8f));   // experience.py:120
   if (norm_value) {
-    values[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(values[i], stats[2]), stats[3]), lo), hi);
-    returns[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(returns[i], stats[4]), stats[5]), lo), hi);
+    values[i] = fminf(fmaxf(div_rn(sub_rn(values[i], stats[2]), stats[3]), lo), hi);
+    returns[i] = fminf(fmaxf(div_rn(sub_rn(returns[i], stats[4]), stats[5]), lo), hi);
   }
 }
 
@@ -465,9 +479,9 @@ __global__ void rms_normalize_kernel(const double* __restrict__ mean, const doub
   float v = x[i];
   if (unnorm) {
     v = fminf(fmaxf(v, lo), hi);                       // normalizers.py:70-73
-    y[i] = __fadd_rn(__fmul_rn(s, v), m);
+    y[i] = add_rn(mul_rn(s, v), m);
   } else {
-    y[i] = fminf(fmaxf(__fdiv_rn(__fsub_rn(v, m), s), lo), hi);   // normalizers.py:65-68
+    y[i] = fminf(fmaxf(div_rn(sub_rn(v, m), s), lo), hi);   // normalizers.py:65-68
   }
 }
 
@@ -551,15 +565,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   __syncthreads();
   const float coef = s_coef;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = __fmul_rn(__fmul_rn(g[i], a.grad_scale), coef);
+    float gi = mul_rn(mul_rn(g[i], a.grad_scale), coef);
     float pi = p[i];
-    if (a.adamw) pi = __fmul_rn(pi, a.lr_wd_mul);
-    else if (a.l2 != 0.f) gi = __fadd_rn(gi, __fmul_rn(a.l2, pi));
+    if (a.adamw) pi = mul_rn(pi, a.lr_wd_mul);
+    else if (a.l2 != 0.f) gi = add_rn(gi, mul_rn(a.l2, pi));
     float mi = m[i], vi = v[i];
-    mi = __fadd_rn(mi, __fmul_rn(a.one_m_b1, __fsub_rn(gi, mi)));                       // exp_avg.lerp_(g, 1-b1)
-    vi = __fadd_rn(__fmul_rn(vi, a.b2), __fmul_rn(__fmul_rn(a.one_m_b2, gi), gi));      // mul_(b2).addcmul_(g,g,1-b2)
-    float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
-    pi = __fadd_rn(pi, __fmul_rn(a.neg_step_size, __fdiv_rn(mi, denom)));                // addcdiv_(m, denom, -step)
+    mi = add_rn(mi, mul_rn(a.one_m_b1, sub_rn(gi, mi)));                       // exp_avg.lerp_(g, 1-b1)
+    vi = add_rn(mul_rn(vi, a.b2), mul_rn(mul_rn(a.one_m_b2, gi), gi));      // mul_(b2).addcmul_(g,g,1-b2)
+    float denom = add_rn(div_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+    pi = add_rn(pi, mul_rn(a.neg_step_size, div_rn(mi, denom)));                // addcdiv_(m, denom, -step)
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
@@ -646,19 +660,19 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
 }
 
 extern "C" int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,
-                                 const uint8_t* time_outs, float reward_scale, float gamma, void* stream) {
+                                 const uint8_t* time_outs, double reward_scale, double gamma, void* stream) {
   if (check_buf(buf)) return MRL_EINVAL;
   if (t < 0 || t >= buf->horizon) MRL_FAIL(MRL_EINVAL, "step %d outside 0..%d", t, buf->horizon - 1);
   if (!rewards || !dones) MRL_FAIL(MRL_EINVAL, "NULL rewards/dones");
   const int64_t N = buf->num_envs;
   hipLaunchKernelGGL(rollout_write_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
                      buf->rewards_tn + (int64_t)t * N, buf->dones_tn + (int64_t)t * N, buf->values_tn + (int64_t)t * N, rewards,
-                     dones, time_outs, N, reward_scale, gamma);
+                     dones, time_outs, N, (float)reward_scale, (float)gamma);
   MRL_CHECK_LAUNCH("mrl_rollout_write");
   return MRL_OK;
 }
 
-extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, float gamma, float tau,
+extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
                               const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
                               void* stream) {
   if (check_buf(buf)) return MRL_EINVAL;
@@ -673,9 +687,9 @@ extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, 
   hipStream_t s = (hipStream_t)stream;
   double* part = (double*)workspace;
   float* stats = (float*)(part + (int64_t)nblocks * 6);
-  const float gamma_tau = (float)((double)gamma * (double)tau);
+  const float gamma_tau = (float)(gamma * tau);   // the reference multiplies the two Python floats first
   hipLaunchKernelGGL(gae_kernel, dim3(nblocks), dim3(64), smem, s, buf->rewards_tn, buf->values_tn, buf->dones_tn,
-                     buf->neglogp_tn, last_values, N, T, gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
+                     buf->neglogp_tn, last_values, N, T, (float)gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
                      buf->neglogp, part);
   hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(256), 0, s, part, nblocks, (double)(N * T),
                      value_rms ? value_rms->mean : nullptr, value_rms ? value_rms->var : nullptr,
@@ -845,6 +859,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     launch_wgrad(p, wp, 2, s);
   }
 
+  // alignment gaps between tensors of the flat gradient are never produced by a kernel: start from zeros
+  // (a fill kernel, not hipMemsetAsync, so that the sequence can be captured in a graph)
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)cdiv(L.total, 1024)), dim3(256), 0, s, grads, L.total);
   // ---- reduce partial slabs into the flat gradient -----------------------------------------------------------------
   ReduceTable tab;
   tab.n = 0;
