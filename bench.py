@@ -1,0 +1,174 @@
+"""PPO env-steps/sec on the synthetic (obs=64, act=12) vectorised env — the metric of BASELINE.json.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" is one full PPO iteration of the hot path: `play_steps` (T=32 policy/env steps into the device rollout
+buffer, bootstrap forward, GAE, advantage / value normalisation) plus `train_epoch` (5 mini-epochs x B/mb optimizer
+steps), hyper-parameters of cfgs/agent/DFlexAntPPO.yaml with minibatch_size 32768, 65536 envs PER GPU (weak
+scaling: 8 GPUs = the 524288-env configuration).  Rank 0 prints one JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_HORIZON = 32
+UNITS = [512, 256, 128]
+OBS, ACT = 64, 12
+# algorithmic work of the MLP towers per env-step: forward MACs/sample 396,416; backward 727,296; per env-step
+# 1 rollout forward + 5 mini-epochs x (forward + backward) = 6,014,976 MAC = 12.03 MFLOP
+FWD_MAC = 2 * (OBS * 512 + 512 * 256 + 256 * 128) + 128 * 2 * ACT + 128
+BWD_MAC = 2 * FWD_MAC - 2 * OBS * 512
+
+
+def make_cfg(num_envs, minibatch, device, multi_gpu, max_steps=10**12):
+    from mineral_amd.config import Config
+    ppo = dict(multi_gpu=multi_gpu, num_actors=num_envs, reward_shaper=dict(fn='scale', scale=1.0), max_agent_steps=max_steps,
+               horizon_len=T_HORIZON, minibatch_size=minibatch, normalize_value=True, value_bootstrap=True, clip_value_loss=False,
+               normalize_advantage=True, gamma=0.99, tau=0.95, entropy_coef=0.0, e_clip=0.2, use_smooth_clamp=False,
+               critic_coef=4, bounds_loss_coef=0.0001, bounds_type='bound', mini_epochs=5, optim_type='AdamW',
+               optim_kwargs=dict(lr=5e-4, eps=1e-5), lr_schedule='kl', kl_threshold=0.008, max_grad_norm=0.5, truncate_grads=True)
+    return Config.wrap(dict(
+        rl_device=device, sim_device=device, multi_gpu=multi_gpu, env_render=False, run='train', seed=42,
+        task=dict(name='Synthetic', suite='synthetic', env=dict(numEnvs=num_envs, obs_dim=OBS, act_dim=ACT, episode_length=1000),
+                  env_autoresets=True),
+        agent=dict(algo='PPO', print_every=-1, ckpt_every=-1, tracker_len=100, metrics_kwargs={},
+                   network=dict(normalize_input=True, actor_critic='ActorCritic',
+                                actor_critic_kwargs=dict(separate_value_mlp=True,
+                                                         mlp_kwargs=dict(units=UNITS, norm_type='LayerNorm', act_type='SiLU'),
+                                                         fixed_sigma=False,
+                                                         actor_dist_kwargs=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0))),
+                   ppo=ppo)))
+
+
+def cpu_baseline(num_envs=16384, minibatch=32768, threads=None):
+    """The CPU oracle (a torch-CPU restatement of the reference, pinned to its golden vectors) on this host's cores:
+    one full PPO iteration on a bounded sample of the same workload."""
+    import torch
+    from mineral_amd.envs.synthetic import SyntheticEnv
+    from oracle import ppo_oracle as O
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.NetConfig(OBS, ACT, UNITS, 'LayerNorm', 'SiLU', False, 'dreamerv3_normal', 0.1, 1.0)
+    params = O.init_params(cfg, torch.Generator().manual_seed(0))
+    hp = O.PPOHParams(minibatch_size=min(minibatch, num_envs * T_HORIZON))
+    env = SyntheticEnv(num_envs, OBS, ACT, 1000, device='cpu', seed=1)
+    obs = env.reset()
+    obs_rms, value_rms = O.rms_init((OBS,)), O.rms_init((1,))
+    st = O.adam_state_init(params)
+    sched = O.AdaptiveScheduler(hp.kl_threshold, hp.min_lr, hp.max_lr)
+    t0 = time.perf_counter()
+    noise = torch.randn(T_HORIZON, num_envs, ACT)
+    data, value_rms, obs = O.play_steps(params, obs_rms, value_rms, env, obs, noise, cfg, hp)
+    O.train_epoch(params, st, obs_rms, data, cfg, hp, hp.lr, sched)
+    dt = time.perf_counter() - t0
+    return {'value': num_envs * T_HORIZON / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 PPO iteration, {num_envs} envs x T={T_HORIZON}, minibatch {hp.minibatch_size}, 5 mini-epochs, '
+                      f'torch-CPU oracle, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--num-envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--minibatch', type=int, default=32768, help='minibatch rows per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    multi = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = f'cuda:{local_rank}'
+    if multi:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    from mineral_amd import _hip
+    from mineral_amd.agents import PPO
+    from mineral_amd.envs import synthetic
+
+    cfg = make_cfg(args.num_envs, args.minibatch, dev, multi)
+    cfg.env_seed = 365838 + rank          # launcher sub-seed 'env_train' of seed 42, offset by rank
+    torch.manual_seed(671155 + rank)      # 'train' sub-seed (action noise)
+    env = synthetic.make_envs(cfg)
+    logdir = os.path.join('/tmp', f'mrl_bench_{os.getpid()}')
+    agent = PPO(cfg, logdir=logdir, accelerator=None, datasets=None, env=env)
+    agent.obs = agent._convert_obs(env.reset())
+
+    def one_step():
+        agent.epoch += 1
+        agent.play_steps()
+        agent.train_epoch()
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = _hip.lib()
+    timing = not args.no_kernel_timing
+    if timing:
+        L.mrl_profile_enable(1)           # warm-up: time every GEMM instantiation to find the dominant one
+    for _ in range(args.warmup):
+        one_step()
+    if timing:
+        torch.cuda.synchronize()
+        L.mrl_profile_enable(2 if args.warmup > 0 else 1)   # timed region: events around the dominant kernel only
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    env_steps = args.num_envs * T_HORIZON * world * args.steps
+    out = {
+        'metric': 'PPO env-steps/sec, synthetic env (obs=64, act=12), 65536 envs per MI355X',
+        'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'PPO DFlexAntPPO hparams, {args.num_envs} envs/GPU x T=32, minibatch {args.minibatch}, '
+                               f'5 mini-epochs, MLP [512,256,128] LayerNorm+SiLU, AdamW, KL-adaptive lr',
+                   'num_envs_total': args.num_envs * world, 'ms_per_update': 1e3 * dt / args.steps,
+                   'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
+    }
+    if rank == 0:
+        if timing:
+            import ctypes as C
+            ms, n, flops = C.c_double(0), C.c_int64(0), C.c_double(0)
+            name = C.create_string_buffer(128)
+            L.mrl_profile_read(C.byref(ms), C.byref(n), C.byref(flops), name, 128)
+            if n.value > 0:
+                achieved = flops.value / (ms.value * 1e-3) / 1e12
+                peak = 157.3
+                out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                                   'traffic': None, 'kernel': name.value.decode(), 'launches': int(n.value),
+                                   'avg_launch_us': 1e3 * ms.value / n.value}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

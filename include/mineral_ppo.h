@@ -160,6 +160,16 @@ int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
                   float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream);
 
+/* Benchmark support, no counterpart in the reference: time the MFMA GEMM launches with HIP events on the stream
+ * they are issued to.  mode 0 = off (default), 1 = every GEMM instantiation, 2 = only the instantiation that has
+ * accumulated the most time so far (call after a mode-1 warm-up); every call drops the data gathered before.
+ * mrl_profile_read waits for the recorded events and reports the instantiation with the largest total time:
+ * summed duration, launch count, summed algorithmic FLOPs (2*M*N*K per launch) and the kernel's name.
+ * Not thread-safe; leave off outside benchmarks. */
+int mrl_profile_enable(int mode);
+int mrl_profile_read(double* total_ms_host, int64_t* launches_host, double* flops_host, char* name_host,
+                     int32_t name_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,8 @@ _SIGNATURES = {
                                C.c_float, _P, _P, _P, C.c_int64, _P]),
     'mrl_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                 C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
+    'mrl_profile_enable': (C.c_int, [C.c_int]),
+    'mrl_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -73,6 +75,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HipLibraryError(f'{LIB_PATH} not found: build it with `make` at the repository root '
                                   '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+        # torch ships its own HIP runtime; load it first so that the library binds to the same runtime instance
+        # that owns the tensors' device memory and streams
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:

@@ -85,6 +85,11 @@ struct GemmP {
   HeadsP h;
 };
 
+// fast sigmoid on the hardware exp2 / rcp (about 1 ulp each); used where the result feeds fp32 GEMM operands
+__device__ __forceinline__ float sigmoid_fast(float y) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * y));
+}
+
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
 __device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + expf(-y)); }
 
@@ -99,8 +104,39 @@ __device__ __forceinline__ f32x4 apply_pro(f32x4 v, int pro, const float* p0, co
     for (int i = 0; i < 4; ++i) r[i] = fminf(fmaxf((v[i] - a[i]) / b[i], lo), hi);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = silu_f(v[i] * a[i] + b[i]);
+    for (int i = 0; i < 4; ++i) {
+      const float y = v[i] * a[i] + b[i];
+      r[i] = y * sigmoid_fast(y);
+    }
   }
+  return r;
+}
+
+// Reduce V (16 or 32) per-lane values over the 32 lanes of each half-wave with recursive halving: V-1 shuffles
+// instead of 5V.  Returns the total of slot `own` (own = l32 for V == 32, l32 >> 1 for V == 16); v is clobbered.
+template <int N, int MASK>
+struct HalvingStep {
+  // one level: lanes with (l32 & MASK) keep the upper half of the N live values, the others the lower half
+  static __device__ __forceinline__ void run(float* v, int l32) {
+    if constexpr (N > 1) {
+      const bool up = (l32 & MASK) != 0;
+#pragma unroll
+      for (int j = 0; j < N / 2; ++j) {
+        const float send = up ? v[j] : v[j + N / 2];
+        const float keep = up ? v[j + N / 2] : v[j];
+        v[j] = keep + __shfl_xor(send, MASK);
+      }
+      HalvingStep<N / 2, MASK / 2>::run(v, l32);
+    }
+  }
+};
+
+template <int V>
+__device__ __forceinline__ float halving_sum32(float (&v)[V], int l32) {
+  static_assert(V == 16 || V == 32, "one or two 32x32 accumulator tiles per wave row");
+  HalvingStep<V, 16>::run(v, l32);
+  float r = v[0];
+  if (V == 16) r += __shfl_xor(r, 1);
   return r;
 }
 
@@ -290,8 +326,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
       }
   } else if constexpr (EPI == EPI_LNFWD) {
     // bias, two-pass LayerNorm statistics over the full row (BN == N), store xhat and rstd
-    float* red1 = lds;                 // [BM][WGN]
-    float* red2 = lds + BM * WGN;      // [BM][WGN]
+    constexpr int V = TM * 16;
+    float* partA = lds;                 // [WGN][BM] row sums per wave column
+    float* partB = lds + BM * WGN;      // [WGN][BM] sums of squared deviations
     const float* bias = p.bias[tw];
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
@@ -302,199 +339,179 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         for (int r = 0; r < 16; ++r) acc[im][in][r] += b;
     }
     const float invn = 1.0f / (float)BN;
-    float mean[TM][16];
-#pragma unroll
-    for (int im = 0; im < TM; ++im)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = 0.f;
-#pragma unroll
-        for (int in = 0; in < TN; ++in) s += acc[im][in][r];
-        s = half_sum32(s);
-        if (WGN > 1) {
-          if (l32 == 0) red1[rowof(im, r) * WGN + wn] = s;
-        } else {
-          mean[im][r] = s * invn;
-        }
-      }
-    if (WGN > 1) {
-      __syncthreads();
+    const int own = (V == 32) ? l32 : (l32 >> 1);            // row slot whose total this lane ends up holding
+    const int own_row = wm * TM * 32 + (own >> 4) * 32 + (own & 3) + 8 * ((own & 15) >> 2) + 4 * h;
+    const bool owner = (V == 32) || ((l32 & 1) == 0);
+    {
+      float sv[V];
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float s = 0.f;
+          float t = 0.f;
 #pragma unroll
-          for (int w = 0; w < WGN; ++w) s += red1[rowof(im, r) * WGN + w];
-          mean[im][r] = s * invn;
+          for (int in = 0; in < TN; ++in) t += acc[im][in][r];
+          sv[im * 16 + r] = t;
         }
+      float tot = halving_sum32<V>(sv, l32);
+      if (owner) partA[wn * BM + own_row] = tot;
     }
-    float rstd[TM][16];
-#pragma unroll
-    for (int im = 0; im < TM; ++im)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = 0.f;
-#pragma unroll
-        for (int in = 0; in < TN; ++in) {
-          float d = acc[im][in][r] - mean[im][r];
-          acc[im][in][r] = d;
-          s += d * d;
-        }
-        s = half_sum32(s);
-        if (WGN > 1) {
-          if (l32 == 0) red2[rowof(im, r) * WGN + wn] = s;
-        } else {
-          rstd[im][r] = 1.0f / sqrtf(s * invn + p.ln_eps);
-        }
-      }
-    if (WGN > 1) {
-      __syncthreads();
+    __syncthreads();
+    {
+      float qv[V];
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float s = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
+          f32x4 t = *reinterpret_cast<const f32x4*>(partA + base);
 #pragma unroll
-          for (int w = 0; w < WGN; ++w) s += red2[rowof(im, r) * WGN + w];
-          rstd[im][r] = 1.0f / sqrtf(s * invn + p.ln_eps);
+          for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partA + w * BM + base);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float mean = t[rr] * invn;
+            float sq = 0.f;
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+              float d = acc[im][in][g * 4 + rr] - mean;
+              acc[im][in][g * 4 + rr] = d;
+              sq += d * d;
+            }
+            qv[im * 16 + g * 4 + rr] = sq;
+          }
         }
+      float tot = halving_sum32<V>(qv, l32);
+      if (owner) partB[wn * BM + own_row] = tot;
     }
-    float* out = p.out[tw];
+    __syncthreads();
+    // one per-lane base pointer; every element is then at a compile-time offset from it (ldo == BN here)
+    float* out_lane = p.out[tw] + (int64_t)(m0 + wm * TM * 32 + 4 * h) * BN + wn * TN * 32 + l32;
     float* rs = p.rstd[tw];
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + rowof(im, r);
-        if (row < p.M) {
+      for (int g = 0; g < 4; ++g) {
+        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
+        f32x4 t = *reinterpret_cast<const f32x4*>(partB + base);
 #pragma unroll
-          for (int in = 0; in < TN; ++in) out[(int64_t)row * p.ldo + n0 + colof(in)] = acc[im][in][r] * rstd[im][r];
-          if (wn == 0 && l32 == 0) rs[row] = rstd[im][r];
+        for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partB + w * BM + base);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float rstd = 1.0f / sqrtf(t[rr] * invn + p.ln_eps);
+          const int row = m0 + base + rr;
+          if (row < p.M) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) out_lane[(im * 32 + 8 * g + rr) * BN + in * 32] = acc[im][in][g * 4 + rr] * rstd;
+            if (wn == 0 && l32 == 0) rs[row] = rstd;
+          }
         }
       }
   } else if constexpr (EPI == EPI_LNBWD) {
     // acc = d loss / d h with h = silu(y), y = xhat*gamma + beta, xhat = LayerNorm-normalised z.
     // dy = dh * silu'(y); dxhat = dy*gamma; dz = rstd * (dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)).
-    float* red1 = lds;                         // [BM][WGN]  sum dxhat
-    float* red2 = lds + BM * WGN;              // [BM][WGN]  sum dxhat*xhat
-    float* cred = lds + 2 * BM * WGN;          // [WGM][3][BN] column partials
-    const float* xh = p.xhat[tw];
+    constexpr int V = TM * 16;
+    float* part1 = lds;                        // [WGN][BM]  sum dxhat
+    float* part2 = lds + BM * WGN;             // [WGN][BM]  sum dxhat*xhat
+    float* cred = lds + 2 * BM * WGN;          // [WGM][3][BN] column partials (dgamma, dbeta, dbias)
+    const int64_t lane_off = (int64_t)(m0 + wm * TM * 32 + 4 * h) * BN + wn * TN * 32 + l32;
+    const float* xh_lane = p.xhat[tw] + lane_off;   // element (im, r, in) sits at a compile-time offset from here
+    float* out_lane = p.out[tw] + lane_off;
     const float* gam = p.gamma[tw];
     const float* bet = p.beta[tw];
     const float invn = 1.0f / (float)BN;
-    float cg[TN], cb[TN], cz[TN];
-    float c1[TM][16], c2[TM][16];
+    const int own = (V == 32) ? l32 : (l32 >> 1);
+    const int own_row = wm * TM * 32 + (own >> 4) * 32 + (own & 3) + 8 * ((own & 15) >> 2) + 4 * h;
+    const bool owner = (V == 32) || ((l32 & 1) == 0);
+    {
+      float c1[V], c2[V];
 #pragma unroll
-    for (int im = 0; im < TM; ++im)
+      for (int v = 0; v < V; ++v) c1[v] = c2[v] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c1[im][r] = c2[im][r] = 0.f;
+      for (int in = 0; in < TN; ++in) {
+        const int col = n0 + colof(in);
+        const float g = gam[col], b = bet[col];
+        float sg = 0.f, sb = 0.f;
 #pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      int col = n0 + colof(in);
-      float g = gam[col], b = bet[col];
-      float sg = 0.f, sb = 0.f;
+        for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = m0 + rowof(im, r);
-          float x = 0.f, dxh = 0.f;
-          if (row < p.M) {
-            x = xh[(int64_t)row * p.ldo + col];
-            float y = x * g + b;
-            float s = sigmoid_f(y);
-            float dy = acc[im][in][r] * (s * (1.0f + y * (1.0f - s)));
-            sg += dy * x;
-            sb += dy;
-            dxh = dy * g;
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + rowof(im, r);
+            float x = 0.f, dxh = 0.f;
+            if (row < p.M) {
+              x = xh_lane[(im * 32 + (r & 3) + 8 * (r >> 2)) * BN + in * 32];
+              const float y = x * g + b;
+              const float sgm = sigmoid_fast(y);
+              const float dy = acc[im][in][r] * (sgm * (1.0f + y * (1.0f - sgm)));
+              sg += dy * x;
+              sb += dy;
+              dxh = dy * g;
+            }
+            acc[im][in][r] = dxh;
+            c1[im * 16 + r] += dxh;
+            c2[im * 16 + r] += dxh * x;
+            if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 xhat loads in flight: register pressure
           }
-          acc[im][in][r] = dxh;
-          c1[im][r] += dxh;
-          c2[im][r] += dxh * x;
+        sg += __shfl_xor(sg, 32);
+        sb += __shfl_xor(sb, 32);
+        if (h == 0) {
+          cred[(wm * 3 + 0) * BN + colof(in)] = sg;
+          cred[(wm * 3 + 1) * BN + colof(in)] = sb;
         }
-      cg[in] = sg;
-      cb[in] = sb;
-    }
-#pragma unroll
-    for (int im = 0; im < TM; ++im)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s1 = half_sum32(c1[im][r]), s2 = half_sum32(c2[im][r]);
-        if (WGN > 1) {
-          if (l32 == 0) {
-            red1[rowof(im, r) * WGN + wn] = s1;
-            red2[rowof(im, r) * WGN + wn] = s2;
-          }
-        } else {
-          c1[im][r] = s1 * invn;
-          c2[im][r] = s2 * invn;
-        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next column's loads from being hoisted (register pressure)
       }
-    if (WGN > 1) {
-      __syncthreads();
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < WGN; ++w) {
-            s1 += red1[rowof(im, r) * WGN + w];
-            s2 += red2[rowof(im, r) * WGN + w];
-          }
-          c1[im][r] = s1 * invn;
-          c2[im][r] = s2 * invn;
-        }
+      float t1 = halving_sum32<V>(c1, l32);
+      float t2 = halving_sum32<V>(c2, l32);
+      if (owner) {
+        part1[wn * BM + own_row] = t1;
+        part2[wn * BM + own_row] = t2;
+      }
     }
-    float* out = p.out[tw];
+    __syncthreads();
     const float* rs = p.rstd[tw];
-    float rstd[TM][16];
+    float cz[TN];
+#pragma unroll
+    for (int in = 0; in < TN; ++in) cz[in] = 0.f;
 #pragma unroll
     for (int im = 0; im < TM; ++im)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = m0 + rowof(im, r);
-        rstd[im][r] = row < p.M ? rs[row] : 0.f;
-      }
+      for (int g = 0; g < 4; ++g) {
+        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
+        f32x4 t1 = *reinterpret_cast<const f32x4*>(part1 + base);
+        f32x4 t2 = *reinterpret_cast<const f32x4*>(part2 + base);
 #pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      int col = n0 + colof(in);
-      float sz = 0.f;
+        for (int w = 1; w < WGN; ++w) {
+          t1 += *reinterpret_cast<const f32x4*>(part1 + w * BM + base);
+          t2 += *reinterpret_cast<const f32x4*>(part2 + w * BM + base);
+        }
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = m0 + rowof(im, r);
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = m0 + base + rr;
           if (row < p.M) {
-            float x = xh[(int64_t)row * p.ldo + col];
-            float dz = rstd[im][r] * (acc[im][in][r] - c1[im][r] - x * c2[im][r]);
-            out[(int64_t)row * p.ldo + col] = dz;
-            sz += dz;
+            const float rstd = rs[row];
+            const float m1 = t1[rr] * invn, m2 = t2[rr] * invn;
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+              const float x = xh_lane[(im * 32 + 8 * g + rr) * BN + in * 32];
+              const float dz = rstd * (acc[im][in][g * 4 + rr] - m1 - x * m2);
+              out_lane[(im * 32 + 8 * g + rr) * BN + in * 32] = dz;
+              cz[in] += dz;
+            }
           }
         }
-      cz[in] = sz;
-    }
-    // column partial sums: combine the two half-waves, then the WGM waves that share a column
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      float g = cg[in] + __shfl_xor(cg[in], 32);
-      float b = cb[in] + __shfl_xor(cb[in], 32);
       float z = cz[in] + __shfl_xor(cz[in], 32);
-      if (h == 0) {
-        int col = colof(in);
-        cred[(wm * 3 + 0) * BN + col] = g;
-        cred[(wm * 3 + 1) * BN + col] = b;
-        cred[(wm * 3 + 2) * BN + col] = z;
-      }
+      if (h == 0) cred[(wm * 3 + 2) * BN + colof(in)] = z;
     }
     __syncthreads();
     float* cp = p.colpart[tw] + (int64_t)blockIdx.x * 3 * BN;
     for (int i = tid; i < 3 * BN; i += 256) {
-      float s = 0.f;
+      float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < WGM; ++w) s += cred[w * 3 * BN + i];
-      cp[i] = s;
+      for (int w = 0; w < WGM; ++w) sum += cred[w * 3 * BN + i];
+      cp[i] = sum;
     }
   } else if constexpr (EPI == EPI_HEADS_TRAIN || EPI == EPI_HEADS_ACT) {
     static_assert(TN == 1 && WGN == 1 && TM == 1, "heads use a 32-wide tile, one 32x32 block per wave");

@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <utility>
+#include <vector>
+
 using namespace mrl;
 
 static thread_local char g_err[512] = "";
@@ -107,7 +110,7 @@ static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
   w.bn = (w.bm == 32) ? 128 : (gn <= 64 ? 64 : 128);
   w.tiles_m = (int)cdiv(gm, w.bm);
   w.tiles_n = (int)cdiv(gn, w.bn);
-  int64_t want = cdiv(768, (int64_t)w.tiles_m * w.tiles_n * 2);
+  int64_t want = cdiv(512, (int64_t)w.tiles_m * w.tiles_n * 2);
   int64_t ks = cdiv(cdiv(rows, want), 16) * 16;
   if (ks < 64) ks = 64;
   w.ksplit = (int)ks;
@@ -166,9 +169,96 @@ extern "C" int64_t mrl_workspace_bytes(const mrl_net* net, int64_t rows) {
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM launch helpers
 // ---------------------------------------------------------------------------------------------------------------
+// ---- optional per-kernel timing with HIP events (benchmarks only; off by default, not thread-safe) ---------------
+// mode 1 times every GEMM instantiation, mode 2 only the one that has accumulated the most time so far.
+struct ProfClass {
+  char name[96];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double flops = 0;
+};
+static std::vector<ProfClass> g_prof;
+static int g_prof_mode = 0, g_prof_only = -1;
+
+static int prof_register(const char* name) {
+  g_prof.emplace_back();
+  snprintf(g_prof.back().name, sizeof(g_prof.back().name), "%s", name);
+  return (int)g_prof.size() - 1;
+}
+
+static double prof_total_ms(ProfClass& c) {
+  double t = 0;
+  for (auto& e : c.ev) {
+    float ms = 0;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) t += ms;
+  }
+  return t;
+}
+
+static void prof_clear() {
+  for (auto& c : g_prof) {
+    for (auto& e : c.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    c.ev.clear();
+    c.flops = 0;
+  }
+}
+
+extern "C" int mrl_profile_enable(int mode) {
+  if (mode < 0 || mode > 2) MRL_FAIL(MRL_EINVAL, "profile mode %d", mode);
+  if (mode == 2) {
+    int best = -1;
+    double bt = -1;
+    for (size_t i = 0; i < g_prof.size(); ++i) {
+      double t = prof_total_ms(g_prof[i]);
+      if (t > bt) { bt = t; best = (int)i; }
+    }
+    g_prof_only = best;
+    if (best < 0) mode = 1;
+  }
+  prof_clear();
+  g_prof_mode = mode;
+  return MRL_OK;
+}
+
+extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flops, char* name, int32_t name_len) {
+  if (!total_ms || !launches || !flops) MRL_FAIL(MRL_EINVAL, "NULL output");
+  int best = -1;
+  double bt = -1;
+  for (size_t i = 0; i < g_prof.size(); ++i) {
+    if (g_prof[i].ev.empty()) continue;
+    double t = prof_total_ms(g_prof[i]);
+    if (t > bt) { bt = t; best = (int)i; }
+  }
+  *total_ms = 0; *launches = 0; *flops = 0;
+  if (best < 0) return MRL_OK;
+  *total_ms = bt;
+  *launches = (int64_t)g_prof[best].ev.size();
+  *flops = g_prof[best].flops;
+  if (name && name_len > 0) snprintf(name, name_len, "%s", g_prof[best].name);
+  return MRL_OK;
+}
+
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
+  static int cls = [] {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI);
+    return prof_register(nm);
+  }();
+  const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+  }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI>), grid, dim3(256), 0, s, p);
+  if (timed) {
+    (void)hipEventRecord(e1, s);
+    ProfClass& c = g_prof[cls];
+    c.ev.emplace_back(e0, e1);
+    for (unsigned z = 0; z < grid.z; ++z)   // algorithmic FLOPs of the launch: 2*M*N*K with the true (unpadded) sizes
+      c.flops += 2.0 * p.M * (p.Nt[z] ? p.Nt[z] : p.N) * (double)((EPI != EPI_SLAB && p.Kt[z]) ? p.Kt[z] : p.K);
+  }
 }
 
 // full-row tiles, selected by the output width
@@ -492,22 +582,39 @@ struct ReduceTable { ReduceDesc d[MRL_MAX_RDESC]; int n; };
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
   const ReduceDesc d = tab.d[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < d.nslabs; ++k) s += d.src[k * d.stride + i];
-    d.dst[i] = s;
+  if ((d.count & 3) == 0 && (d.stride & 3) == 0) {
+    const int64_t n4 = d.count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k = 0; k < d.nslabs; ++k) s += *reinterpret_cast<const f32x4*>(d.src + k * d.stride + 4 * i);
+      *reinterpret_cast<f32x4*>(d.dst + 4 * i) = s;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      for (int k = 0; k < d.nslabs; ++k) s += d.src[k * d.stride + i];
+      d.dst[i] = s;
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void metrics_final_kernel(const double* __restrict__ part, int nblocks, double mb,
-                                                           float critic_coef, float entropy_coef, float bounds_coef,
-                                                           double* __restrict__ out) {
-  // part [nblocks][2][NMETRIC]; fixed-order sums so results are reproducible
+__global__ __launch_bounds__(192) void metrics_final_kernel(const double* __restrict__ part, int nblocks, double mb,
+                                                            float critic_coef, float entropy_coef, float bounds_coef,
+                                                            double* __restrict__ out) {
+  // part [nblocks][2][NMETRIC]; 16 threads per metric, fixed-order sums so results are reproducible
+  __shared__ double red[16][MRL_NMETRIC];
   __shared__ double s[MRL_NMETRIC];
+  const int m = threadIdx.x % MRL_NMETRIC, j = threadIdx.x / MRL_NMETRIC;
+  double a = 0;
+  for (int b = j; b < nblocks; b += 16)
+    a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + m] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + m];
+  red[j][m] = a;
+  __syncthreads();
   if (threadIdx.x < MRL_NMETRIC) {
-    double a = 0;
-    for (int b = 0; b < nblocks; ++b) a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + threadIdx.x] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + threadIdx.x];
-    s[threadIdx.x] = a;
+    double t = 0;
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    s[threadIdx.x] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -803,7 +910,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
     launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN>(p, dim3(hblocks, 1, 2), s);
   }
-  hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(64), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
+  hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
                      hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
 
   // ---- backward: dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) -----------------
@@ -885,8 +992,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     add(ws + W.headb_part + tw * 32, L.bh[tw], hn, 64, hblocks);
   }
   {
-    int gx = (int)cdiv(maxcount, 256);
-    if (gx > 128) gx = 128;
+    int gx = (int)cdiv(maxcount, 1024);
+    if (gx > 256) gx = 256;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
   }
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
