@@ -126,6 +126,16 @@ int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, double gamm
                    const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
+/* The two halves of mrl_gae_finish, for runs where the envs are sharded over ranks: mrl_gae_scan does the scan and
+ * the flattening and leaves sums_out[6] = sum of advantages, advantages^2, values, values^2, returns, returns^2 of
+ * THIS rank's samples (fp64, device); the caller all-reduces them, and mrl_gae_normalize (count = samples of all
+ * ranks) then normalises with the global statistics, so value_rms stays identical on every rank.
+ * stats_out is required here (8 floats, device). */
+int mrl_gae_scan(const mrl_rollout* buf, const float* last_values, double gamma, double tau, double* sums_out,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, double count, const mrl_rms* value_rms,
+                      float* stats_out, void* stream);
+
 /* Batch moments of x [rows][cols] per group of `group_rows` consecutive rows: mean (fp32) and variance with the
  * given correction (fp32), as x.mean(0) / x.var(0, correction) in RunningMeanStd.update
  * (normalizers.py:57-63).  Outputs are [rows/group_rows][cols]. */

@@ -38,6 +38,7 @@ class ExperienceBuffer:
         self._flat = {k: torch.zeros(N * T, **f32) for k in ('values', 'returns', 'advantages', 'neglogp')}
         self.last_values = torch.zeros(N, **f32)
         self.stats = torch.zeros(8, **f32)
+        self._sums = torch.zeros(6, dtype=torch.float64, device=dev)
         self._ws = torch.empty(((N + 63) // 64) * 48 + 4096, dtype=torch.uint8, device=dev)
         self.data_dict = None
         self.last_range = None
@@ -63,13 +64,22 @@ class ExperienceBuffer:
         _hip.check(_hip.lib().mrl_rollout_write(self.c, t, _hip.ptr(rewards.contiguous()), _hip.ptr(d8.contiguous()),
                                                 _hip.ptr(to8), reward_scale, gamma, self._stream()), 'mrl_rollout_write')
 
-    def compute_return(self, last_values, gamma, tau, value_rms=None):
+    def compute_return(self, last_values, gamma, tau, value_rms=None, all_reduce=None, world_size=1):
         """experience.py:96-108 fused with prepare_training (:110-121) and the value normalisation of
-        ppo.py:175-183 when `value_rms` is given."""
+        ppo.py:175-183 when `value_rms` is given.  With `all_reduce` (a callable summing a device tensor over the
+        ranks in place) the advantage / value statistics are those of the envs of ALL ranks."""
         lv = last_values.reshape(-1).contiguous()
         rms = value_rms.c_struct() if value_rms is not None else None
-        _hip.check(_hip.lib().mrl_gae_finish(self.c, _hip.ptr(lv), gamma, tau, rms, _hip.ptr(self.stats), _hip.ptr(self._ws),
-                                             self._ws.numel(), self._stream()), 'mrl_gae_finish')
+        L, s = _hip.lib(), self._stream()
+        if all_reduce is None:
+            _hip.check(L.mrl_gae_finish(self.c, _hip.ptr(lv), gamma, tau, rms, _hip.ptr(self.stats), _hip.ptr(self._ws),
+                                        self._ws.numel(), s), 'mrl_gae_finish')
+            return
+        _hip.check(L.mrl_gae_scan(self.c, _hip.ptr(lv), gamma, tau, _hip.ptr(self._sums), _hip.ptr(self._ws), self._ws.numel(), s),
+                   'mrl_gae_scan')
+        all_reduce(self._sums)
+        count = float(self.num_envs * self.transitions_per_env * world_size)
+        _hip.check(L.mrl_gae_normalize(self.c, _hip.ptr(self._sums), count, rms, _hip.ptr(self.stats), s), 'mrl_gae_normalize')
 
     def prepare_training(self):
         """Flattened views, keys as experience.py:110-121 (no copies: the storage is already env-major)."""

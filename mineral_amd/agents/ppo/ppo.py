@@ -14,7 +14,7 @@ import re
 
 import torch
 
-from ... import _hip
+from ... import _hip, parallel
 from ...common import normalizers
 from ...common.reward_shaper import RewardShaper
 from ...common.timer import Timer
@@ -196,7 +196,9 @@ class PPO(Agent):
         self.metrics.flush_video(self.epoch)
         self.model_act(self.obs, self.horizon_len, last_values=self.storage.last_values)   # ppo.py:169-170
         self.storage.compute_return(self.storage.last_values, self.gamma, self.tau,
-                                    self.value_rms if self.normalize_value else None)     # ppo.py:172-183
+                                    self.value_rms if self.normalize_value else None,     # ppo.py:172-183
+                                    all_reduce=self._dist.all_reduce if self._dist is not None else None,
+                                    world_size=self.rank_size)
         self.storage.prepare_training()
 
     def train(self):
@@ -246,18 +248,7 @@ class PPO(Agent):
         """Combine per-rank minibatch moments (equal counts) so every rank merges identical statistics."""
         if self._dist is None:
             return float(self.minibatch_size)
-        W = self.rank_size
-        mean64, var64 = self._mb_mean.double(), self._mb_var.double()
-        n = float(self.minibatch_size)
-        gm = [torch.empty_like(mean64) for _ in range(W)]
-        gv = [torch.empty_like(var64) for _ in range(W)]
-        self._dist.all_gather(gm, mean64)
-        self._dist.all_gather(gv, var64)
-        gmean = torch.stack(gm).mean(0)
-        m2 = sum(v * (n - 1.0) + n * (m - gmean) ** 2 for m, v in zip(gm, gv))
-        self._mb_mean.copy_(gmean.float())
-        self._mb_var.copy_((m2 / (n * W - 1.0)).float())
-        return n * W
+        return parallel.combine_moments(self._mb_mean, self._mb_var, self.minibatch_size, self._dist, self.rank_size)
 
     def train_epoch(self):
         L = _hip.lib()
@@ -296,7 +287,7 @@ class PPO(Agent):
                                           _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(), s),
                            'mrl_ppo_grad')
                 if self._dist is not None:
-                    self._dist.all_reduce(self.grads)      # the one collective per optimizer step (ppo.py:292)
+                    parallel.average_gradients(self.grads, self._dist)   # the one collective per optimizer step (ppo.py:292)
                 self.optim_step += 1
                 _hip.check(L.mrl_adam_step(_hip.ptr(flat), _hip.ptr(self.grads), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
                                            flat.numel(), self.last_lr, self.betas[0], self.betas[1], self.adam_eps,

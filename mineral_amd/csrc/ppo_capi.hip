@@ -433,45 +433,46 @@ __global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ rewar
   }
 }
 
-// One block: whole-batch advantage statistics and the two-stage value_rms update (ppo.py:175-183,
-// experience.py:119-120).  stats: [0] adv mean [1] adv std [2,3] value mean/std after update 1 [4,5] after update 2.
-__global__ __launch_bounds__(256) void gae_stats_kernel(const double* __restrict__ part, int nblocks, double count,
-                                                        double* rmean, double* rvar, double* rcount, float eps,
-                                                        float* __restrict__ stats) {
+// One block: fixed-order sum of the per-block partials -> sums[6] = sum adv, adv^2, value, value^2, return, return^2.
+__global__ __launch_bounds__(256) void gae_sums_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ sums) {
   __shared__ double red[6][256];
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblocks; b += 256)
     for (int k = 0; k < 6; ++k) acc[k] += part[(int64_t)b * 6 + k];
   for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = acc[k];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double s[6];
-    for (int k = 0; k < 6; ++k) {
-      double x = 0;
-      for (int i = 0; i < 256; ++i) x += red[k][i];
-      s[k] = x;
+  if (threadIdx.x < 6) {
+    double x = 0;
+    for (int i = 0; i < 256; ++i) x += red[threadIdx.x][i];
+    sums[threadIdx.x] = x;
+  }
+}
+
+// Whole-batch advantage statistics and the two-stage value_rms update (ppo.py:175-183, experience.py:119-120) from the
+// six sums.  stats: [0] adv mean [1] adv std [2,3] value mean/std after update 1 [4,5] after update 2.
+__global__ void gae_stats_kernel(const double* __restrict__ s, double count, double* rmean, double* rvar, double* rcount,
+                                 float eps, float* __restrict__ stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double n = count;
+  const double am = s[0] / n;
+  const double avar = (s[1] - s[0] * s[0] / n) / (n - 1.0);
+  stats[0] = (float)am;
+  stats[1] = (float)sqrt(avar > 0 ? avar : 0.0);
+  if (rmean) {
+    double mean = rmean[0], var = rvar[0], cnt = rcount[0];
+    for (int stage = 0; stage < 2; ++stage) {
+      const double sx = s[2 + 2 * stage], sx2 = s[3 + 2 * stage];
+      // batch moments are fp32 tensors in the reference (x.mean(0), x.var(0, correction=1))
+      const double bm = (double)(float)(sx / n);
+      const double bv = (double)(float)((sx2 - sx * sx / n) / (n - 1.0));
+      const double delta = bm - mean, tot = cnt + n;
+      const double new_mean = mean + delta * n / tot;
+      const double m2 = var * cnt + bv * n + delta * delta * cnt * n / tot;
+      mean = new_mean; var = m2 / tot; cnt = tot;
+      stats[2 + 2 * stage] = (float)mean;
+      stats[3 + 2 * stage] = sqrtf((float)var + eps);
     }
-    double n = count;
-    double am = s[0] / n;
-    double avar = (s[1] - s[0] * s[0] / n) / (n - 1.0);
-    stats[0] = (float)am;
-    stats[1] = (float)sqrt(avar > 0 ? avar : 0.0);
-    if (rmean) {
-      double mean = rmean[0], var = rvar[0], cnt = rcount[0];
-      for (int stage = 0; stage < 2; ++stage) {
-        double sx = s[2 + 2 * stage], sx2 = s[3 + 2 * stage];
-        // batch moments are fp32 tensors in the reference (x.mean(0), x.var(0, correction=1))
-        double bm = (double)(float)(sx / n);
-        double bv = (double)(float)((sx2 - sx * sx / n) / (n - 1.0));
-        double delta = bm - mean, tot = cnt + n;
-        double new_mean = mean + delta * n / tot;
-        double m2 = var * cnt + bv * n + delta * delta * cnt * n / tot;
-        mean = new_mean; var = m2 / tot; cnt = tot;
-        stats[2 + 2 * stage] = (float)mean;
-        stats[3 + 2 * stage] = sqrtf((float)var + eps);
-      }
-      rmean[0] = mean; rvar[0] = var; rcount[0] = cnt;
-    }
+    rmean[0] = mean; rvar[0] = var; rcount[0] = cnt;
   }
 }
 
@@ -779,35 +780,58 @@ extern "C" int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float*
   return MRL_OK;
 }
 
-extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
-                              const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
-                              void* stream) {
+extern "C" int mrl_gae_scan(const mrl_rollout* buf, const float* last_values, double gamma, double tau, double* sums_out,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
   if (check_buf(buf)) return MRL_EINVAL;
-  if (!last_values || !workspace) MRL_FAIL(MRL_EINVAL, "NULL last_values/workspace");
+  if (!last_values || !workspace || !sums_out) MRL_FAIL(MRL_EINVAL, "NULL last_values/workspace/sums_out");
   const int64_t N = buf->num_envs;
   const int T = buf->horizon;
   const int nblocks = (int)cdiv(N, 64);
-  const int64_t need = (int64_t)nblocks * 6 * 8 + 64;
+  const int64_t need = (int64_t)nblocks * 6 * 8;
   if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
   size_t smem = (size_t)4 * 64 * (T + 1) * sizeof(float);
   if (smem > 64 * 1024) MRL_FAIL(MRL_EINVAL, "horizon %d too long for the scan tile", T);
   hipStream_t s = (hipStream_t)stream;
   double* part = (double*)workspace;
-  float* stats = (float*)(part + (int64_t)nblocks * 6);
   const float gamma_tau = (float)(gamma * tau);   // the reference multiplies the two Python floats first
   hipLaunchKernelGGL(gae_kernel, dim3(nblocks), dim3(64), smem, s, buf->rewards_tn, buf->values_tn, buf->dones_tn,
                      buf->neglogp_tn, last_values, N, T, (float)gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
                      buf->neglogp, part);
-  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(256), 0, s, part, nblocks, (double)(N * T),
-                     value_rms ? value_rms->mean : nullptr, value_rms ? value_rms->var : nullptr,
-                     value_rms ? value_rms->count : nullptr, value_rms ? value_rms->eps : 0.f, stats);
-  const int64_t B = N * T;
-  hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, s, buf->advantages, buf->values,
-                     buf->returns, stats, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
-                     value_rms ? value_rms->clamp_hi : 0.f);
-  if (stats_out) hipMemcpyAsync(stats_out, stats, 8 * sizeof(float), hipMemcpyDeviceToDevice, s);
-  MRL_CHECK_LAUNCH("mrl_gae_finish");
+  hipLaunchKernelGGL(gae_sums_kernel, dim3(1), dim3(256), 0, s, part, nblocks, sums_out);
+  MRL_CHECK_LAUNCH("mrl_gae_scan");
   return MRL_OK;
+}
+
+extern "C" int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, double count, const mrl_rms* value_rms,
+                                 float* stats_out, void* stream) {
+  if (check_buf(buf)) return MRL_EINVAL;
+  if (!sums || !stats_out) MRL_FAIL(MRL_EINVAL, "NULL sums/stats_out");
+  if (count < 2) MRL_FAIL(MRL_EINVAL, "count %g < 2", count);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(64), 0, s, sums, count, value_rms ? value_rms->mean : nullptr,
+                     value_rms ? value_rms->var : nullptr, value_rms ? value_rms->count : nullptr,
+                     value_rms ? value_rms->eps : 0.f, stats_out);
+  const int64_t B = buf->num_envs * (int64_t)buf->horizon;
+  hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, s, buf->advantages, buf->values,
+                     buf->returns, stats_out, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
+                     value_rms ? value_rms->clamp_hi : 0.f);
+  MRL_CHECK_LAUNCH("mrl_gae_normalize");
+  return MRL_OK;
+}
+
+extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
+                              const mrl_rms* value_rms, float* stats_out, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+  if (check_buf(buf)) return MRL_EINVAL;
+  if (!workspace) MRL_FAIL(MRL_EINVAL, "NULL workspace");
+  const int nblocks = (int)cdiv(buf->num_envs, 64);
+  const int64_t need = (int64_t)nblocks * 6 * 8 + 6 * 8 + 8 * 4;
+  if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  double* sums = (double*)workspace + (int64_t)nblocks * 6;
+  float* stats = stats_out ? stats_out : (float*)(sums + 6);
+  int rc = mrl_gae_scan(buf, last_values, gamma, tau, sums, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return mrl_gae_normalize(buf, sums, (double)(buf->num_envs * (int64_t)buf->horizon), value_rms, stats, stream);
 }
 
 extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int64_t group_rows, int32_t correction,

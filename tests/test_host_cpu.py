@@ -1,0 +1,228 @@
+"""CPU-side checks: the C ABI loads and exports what include/mineral_ppo.h declares, argument validation works
+without a GPU, the host mirrors of the reference interfaces behave, and the sharded (N>1) path is correct under
+gloo with world_size 2."""
+
+import collections
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from oracle import ppo_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'mineral_ppo.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mrl_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from mineral_amd import _hip
+    lib = _hip.lib()
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f'{n} is declared in include/mineral_ppo.h but not exported'
+    assert sorted(_hip.EXPORTS) == names, 'the ctypes binding and the header must list the same entry points'
+    assert lib.mrl_version() >= 1
+
+
+def test_abi_argument_validation_without_gpu():
+    from mineral_amd import _hip
+    L = _hip.lib()
+    net = _hip.make_net(64, 12, [512, 256, 128], 'dreamerv3_normal', 0.1, 1.0)
+    assert L.mrl_param_count(net) == 401820        # 401,817 parameters + 3 floats of alignment padding
+    assert L.mrl_workspace_bytes(net, 32768) > 0
+    bad = _hip.make_net(63, 12, [512, 256, 128], 'dreamerv3_normal')
+    assert L.mrl_param_count(bad) == -1
+    assert b'obs_dim' in L.mrl_last_error()
+    bad = _hip.make_net(64, 12, [500], 'normal')
+    assert L.mrl_workspace_bytes(bad, 10) == -1
+    with pytest.raises(ValueError):
+        _hip.check(L.mrl_rms_merge(None, None, None, 1.0, None, None, None), 'mrl_rms_merge')
+    with pytest.raises(ValueError):
+        _hip.check(L.mrl_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1, 0.0, 1.0, None, None, None), 'adam')
+    with pytest.raises(NotImplementedError):
+        _hip.make_net(64, 12, [32], 'squashed_normal')
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from mineral_amd import _hip
+    monkeypatch.setattr(_hip, '_lib', None)
+    monkeypatch.setattr(_hip, 'LIB_PATH', '/nonexistent/libmineral_ppo.so')
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.lib()
+
+
+def test_parameter_views_match_reference_names_and_count():
+    from mineral_amd.agents.ppo.models import ActorCritic
+    m = ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[512, 256, 128], norm_type='LayerNorm', act_type='SiLU'),
+                    fixed_sigma=False, actor_dist_kwargs=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0), device='cpu')
+    shapes = synth.actor_critic_shapes(64, 12, [512, 256, 128], True, True, False)
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in shapes]
+    assert all(tuple(v.shape) == s for (_, v), (_, s) in zip(m.named_parameters(), shapes))
+    assert sum(v.numel() for v in m.parameters()) == 401817
+    # init statistics of models.py:75-91: orthogonal rows, zero biases, unit LayerNorm gains
+    sd = m.state_dict()
+    w = sd['actor_mlp.mlp.3.weight']
+    assert torch.allclose(w @ w.t(), 2.0 * torch.eye(256), atol=1e-4)
+    assert torch.allclose(sd['mu.weight'] @ sd['mu.weight'].t(), 1e-4 * torch.eye(12), atol=1e-7)
+    assert float(sd['value.bias'].abs().sum()) == 0 and torch.all(sd['value_mlp.mlp.1.weight'] == 1)
+    # views alias the flat vector
+    params = synth.make_params(shapes, 3)
+    m.load_state_dict(params)
+    flat2 = m.flat.clone()
+    assert torch.equal(m.views_of(flat2)['sigma.bias'], params['sigma.bias'])
+    with pytest.raises(NotImplementedError):
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ELU'), fixed_sigma=True, device='cpu')
+
+
+def test_schedulers_match_reference_tables(golden):
+    from mineral_amd.agents.ppo.utils import AdaptiveScheduler, LinearScheduler, adjust_learning_rate_cos
+    g = golden('g9_g10_seeds_sched')
+    sch = AdaptiveScheduler(0.008, 1e-6, 1e-2)
+    lr, lrs = 5e-4, []
+    for k in synth.lcg((40,), 77, 0.04, np.float64) + 0.02:
+        lr = sch.update(lr, float(k))
+        lrs.append(lr)
+    assert np.array_equal(np.array(lrs), g['kl_lrs'])
+    lin = LinearScheduler(5e-4, 1e-6, 1000000)
+    assert np.array_equal(np.array([lin.update(s) for s in range(0, 1200000, 100000)]), g['lin_lrs'])
+    cos = [adjust_learning_rate_cos(5e-4, e, 5, s, 4100000) for e in range(5) for s in (0, 1000000, 4000000)]
+    assert np.array_equal(np.array(cos), g['cos_lrs'])
+
+
+def test_device_metrics_window_equals_deque_semantics():
+    """mineral/common/metrics.py:59-67 + tracker.py: window of the last L finished episodes, env order, no sync."""
+    from mineral_amd.common.metrics import Metrics
+    N, L = 37, 10
+    scores = {'rewards': torch.zeros(N), 'lengths': torch.zeros(N, dtype=torch.int64)}
+    m = Metrics(scores, L)
+    ref_r, ref_l = collections.deque([0] * L, maxlen=L), collections.deque([0] * L, maxlen=L)
+    cur_r, cur_l = np.zeros(N), np.zeros(N, dtype=np.int64)
+    rng = np.random.RandomState(0)
+    total = 0
+    for step in range(40):
+        r = torch.from_numpy(rng.randn(N).astype(np.float32))
+        p = 0.9 if step == 17 else 0.15      # one step finishes more episodes than the window holds
+        d = torch.from_numpy(rng.rand(N) < p)
+        m.update(0, None, None, r, d)
+        cur_r += r.numpy().astype(np.float64)
+        cur_l += 1
+        idx = np.nonzero(d.numpy())[0]
+        ref_r.extend(np.float32(cur_r[idx]).tolist())
+        ref_l.extend(cur_l[idx].tolist())
+        cur_r[idx] = 0
+        cur_l[idx] = 0
+        total += len(idx)
+    assert m.num_episodes == total
+    np.testing.assert_allclose(m.episode_trackers['rewards'].window, list(ref_r), rtol=1e-5, atol=1e-6)
+    assert [int(x) for x in m.episode_trackers['lengths'].window] == list(ref_l)
+    assert abs(m.episode_trackers['rewards'].mean() - float(np.mean(ref_r))) < 1e-5
+
+
+def test_config_tree_access_patterns():
+    from mineral_amd.config import Config
+    c = Config.wrap({'agent': {'ppo': {'e_clip': 0.2, 'optim_kwargs': {'lr': 5e-4}}}, 'x': [1, {'y': 2}]})
+    assert c.agent.ppo.e_clip == 0.2 and c['agent']['ppo'].get('missing', 7) == 7 and c.agent.ppo.optim_kwargs.get('lr') == 5e-4
+    assert c.x[1].y == 2
+    with pytest.raises(AttributeError):
+        c.nope
+    assert c.to_container()['agent']['ppo']['optim_kwargs'] == {'lr': 5e-4}
+
+
+def test_timer_statistics():
+    from mineral_amd.common.timer import Timer
+    t = Timer()
+
+    class Obj:
+        def work(self):
+            return 3
+
+    o = Obj()
+    t.wrap('agent', o, ['work'])
+    assert o.work() == 3 and o.work() == 3
+    st = t.stats(step=100, total_names=('agent.work',), reset=False)
+    assert st['agent.work/count'] == 2 and st['totalrate'] > 0 and 'agent.work/avg' in st
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world_size 2 under gloo: moment merging and gradient averaging of the sharded path
+# ---------------------------------------------------------------------------------------------------------------------
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from mineral_amd import parallel
+    try:
+        # (1) per-minibatch observation moments: each rank holds its own rows of every minibatch
+        n_mb, mb, O_ = 3, 40, 6
+        full = synth.gaussianish((n_mb, world * mb, O_), 31) * 2.0 + 0.7
+        mine = full[:, rank * mb:(rank + 1) * mb]
+        mean, var = mine.mean(1).float(), mine.var(1, correction=1).float()
+        cnt = parallel.combine_moments(mean, var, mb, dist, world)
+        assert cnt == world * mb
+        np.testing.assert_allclose(mean.numpy(), full.mean(1).numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(var.numpy(), full.var(1, correction=1).numpy(), rtol=1e-5, atol=1e-6)
+        # every rank must hold the same bits, or the replicas' normalisers drift apart
+        both = [torch.empty_like(var) for _ in range(world)]
+        dist.all_gather(both, var)
+        assert torch.equal(both[0], both[1])
+
+        # (2) one optimizer step: shard-local gradients, summed over ranks and scaled by 1/W, equal the gradient of the
+        # union minibatch (the DDP all-reduce of mineral/agents/ppo/ppo.py:292)
+        spec = dict(obs=8, act=3, units=[16, 8])
+        shapes = synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], True, True, False)
+        cfg = O.NetConfig(spec['obs'], spec['act'], spec['units'], 'LayerNorm', 'SiLU', False, 'dreamerv3_normal', 0.1, 1.0)
+        hp = O.PPOHParams(minibatch_size=32, normalize_input=False)
+        Bt = 64
+        data = {'obs': synth.gaussianish((Bt, 8), 1), 'actions': synth.gaussianish((Bt, 3), 2) * 0.5,
+                'mu': torch.tanh(synth.gaussianish((Bt, 3), 3)), 'sigma': synth.lcg_t((Bt, 3), 4) * 0.5 + 0.5,
+                'neglogp': synth.gaussianish((Bt,), 5) * 0.3 + 3.0, 'advantages': synth.gaussianish((Bt,), 6),
+                'returns': synth.gaussianish((Bt, 1), 7), 'values': synth.gaussianish((Bt, 1), 8)}
+        shard = {k: v[rank * 32:(rank + 1) * 32] for k, v in data.items()}
+
+        def hook(grads):
+            flat = torch.cat([g.reshape(-1) for g in grads.values()])
+            parallel.average_gradients(flat, dist)
+            flat *= 1.0 / world
+            out, o = collections.OrderedDict(), 0
+            for k, g in grads.items():
+                out[k] = flat[o:o + g.numel()].view_as(g)
+                o += g.numel()
+            return out
+
+        p_shard = synth.make_params(shapes, 2)
+        O.minibatch_step(p_shard, O.adam_state_init(p_shard), None, shard, cfg, hp, 5e-4, grad_hook=hook)
+        p_full = synth.make_params(shapes, 2)
+        hp_full = O.PPOHParams(minibatch_size=64, normalize_input=False)
+        O.minibatch_step(p_full, O.adam_state_init(p_full), None, data, cfg, hp_full, 5e-4)
+        for k in p_full:
+            np.testing.assert_allclose(p_shard[k].numpy(), p_full[k].numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+        q.put((rank, 'ok'))
+    except Exception as e:   # surface the failure in the parent
+        q.put((rank, f'{type(e).__name__}: {e}'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_path_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, 'ok'), (1, 'ok')], results
