@@ -64,7 +64,6 @@ struct GemmP {
   int M, N, K;                 // GEMM sizes (M rows, N cols, K reduction); all loads are guarded by these
   int Nt[2], Kt[2];            // per-tower valid N / K (the heads differ: 2*act_dim vs 1); 0 = use N / K
   int tw0;                     // role of blockIdx.z == 0: 0 actor, 1 critic (critic-only launches)
-  int a_pro, b_pro;            // prologue applied to A / B elements, by the element's column in its matrix
   const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU: gamma[f]
   const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU: beta[f]
   float clamp_lo, clamp_hi;
@@ -93,24 +92,8 @@ __device__ __forceinline__ float sigmoid_fast(float y) {
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
 __device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + expf(-y)); }
 
-__device__ __forceinline__ f32x4 apply_pro(f32x4 v, int pro, const float* p0, const float* p1, int col, float lo,
-                                           float hi) {
-  if (pro == PRO_NONE) return v;
-  f32x4 a = *reinterpret_cast<const f32x4*>(p0 + col);
-  f32x4 b = *reinterpret_cast<const f32x4*>(p1 + col);
-  f32x4 r;
-  if (pro == PRO_NORM) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fminf(fmaxf((v[i] - a[i]) / b[i], lo), hi);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float y = v[i] * a[i] + b[i];
-      r[i] = y * sigmoid_fast(y);
-    }
-  }
-  return r;
-}
+// start of the last 4-float chunk that holds a valid column when `lim` columns are valid (lim >= 1)
+__device__ __forceinline__ int last_chunk(int lim) { return ((lim - 1) >> 2) << 2; }
 
 // Reduce V (16 or 32) per-lane values over the 32 lanes of each half-wave with recursive halving: V-1 shuffles
 // instead of 5V.  Returns the total of slot `own` (own = l32 for V == 32, l32 >> 1 for V == 16); v is clobbered.
@@ -177,10 +160,17 @@ struct GemmCfg {
   static_assert(BK % 8 == 0, "k sub-step is 8");
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
+// PRO: prologue applied while staging — to operand A in the forward kernels (LA == LAY_K), to operand B in wgrad
+// (EPI_SLAB).  The feature index of an element is its column in the stored matrix in both cases.
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
   constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
+  constexpr bool PRO_ON_A = (PRO != PRO_NONE) && (EPI != EPI_SLAB);
+  constexpr bool PRO_ON_B = (PRO != PRO_NONE) && (EPI == EPI_SLAB);
+  static_assert(!PRO_ON_A || LA == LAY_K, "forward prologue expects a k-contiguous A");
+  static_assert(!PRO_ON_B || LB == LAY_R, "wgrad prologue expects a row-reduction B");
+  static_assert(256 % (C::CA / 4) == 0 && 256 % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   float* As = lds;
   float* Bs = lds + C::RA * SA;
@@ -214,65 +204,98 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+  // staging: thread `tid` owns column chunk cA / cB (4 floats) of rows rA0 + i*RSTEP of each tile
+  constexpr int A_RSTEP = 256 / (C::CA / 4), B_RSTEP = 256 / (C::CB / 4);
+  const int cA = (tid % (C::CA / 4)) * 4, rA0 = tid / (C::CA / 4);
+  const int cB = (tid % (C::CB / 4)) * 4, rB0 = tid / (C::CB / 4);
   f32x4 ra[C::A_F4], rb[C::B_F4];
+  f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};   // prologue vectors of this thread's column chunk
+  if constexpr (PRO_ON_B) {   // wgrad: the feature index n0 + cB does not change along the reduction
+    const int gc = min(n0 + cB, last_chunk(Nv));
+    pv0 = *reinterpret_cast<const f32x4*>(pro0 + gc);
+    pv1 = *reinterpret_cast<const f32x4*>(pro1 + gc);
+  }
 
+  // Loads are unconditional (addresses clamped into the matrix) so that they issue back to back; out-of-range
+  // elements are zeroed when the tile is written to LDS.
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < C::A_F4; ++i) {
-      int idx = tid + i * 256;
-      int r = idx / (C::CA / 4), c = (idx % (C::CA / 4)) * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < C::RA * C::CA / 4) {
-        int grow = (LA == LAY_K) ? m0 + r : k0 + r;
-        int gcol = (LA == LAY_K) ? k0 + c : m0 + c;
-        int rlim = (LA == LAY_K) ? p.M : kend;
-        int clim = (LA == LAY_K) ? kend : p.M;
-        if (grow < rlim && gcol < clim) {
-          v = *reinterpret_cast<const f32x4*>(Ag + (int64_t)grow * p.lda + gcol);
-          v = apply_pro(v, p.a_pro, pro0, pro1, gcol, p.clamp_lo, p.clamp_hi);
-        }
+      const int r = rA0 + i * A_RSTEP;
+      if (r < C::RA) {
+        const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
+        const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
+        const int rlim = (LA == LAY_K) ? p.M : kend;
+        const int clim = (LA == LAY_K) ? kend : p.M;
+        ra[i] = *reinterpret_cast<const f32x4*>(Ag + (int64_t)min(grow, rlim - 1) * p.lda + min(gcol, last_chunk(clim)));
       }
-      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < C::B_F4; ++i) {
-      int idx = tid + i * 256;
-      int r = idx / (C::CB / 4), c = (idx % (C::CB / 4)) * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < C::RB * C::CB / 4) {
-        int grow = (LB == LAY_K) ? n0 + r : k0 + r;
-        int gcol = (LB == LAY_K) ? k0 + c : n0 + c;
-        int rlim = (LB == LAY_K) ? Nv : kend;
-        int clim = (LB == LAY_K) ? kend : Nv;
-        if (grow < rlim && gcol < clim) {
-          v = *reinterpret_cast<const f32x4*>(Bg + (int64_t)grow * p.ldb + gcol);
-          v = apply_pro(v, p.b_pro, pro0, pro1, gcol, p.clamp_lo, p.clamp_hi);
-        }
+      const int r = rB0 + i * B_RSTEP;
+      if (r < C::RB) {
+        const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
+        const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
+        const int rlim = (LB == LAY_K) ? Nv : kend;
+        const int clim = (LB == LAY_K) ? kend : Nv;
+        rb[i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(grow, rlim - 1) * p.ldb + min(gcol, last_chunk(clim)));
       }
-      rb[i] = v;
+    }
+    if constexpr (PRO_ON_A) {
+      const int gc = min(k0 + cA, last_chunk(kend));
+      pv0 = *reinterpret_cast<const f32x4*>(pro0 + gc);
+      pv1 = *reinterpret_cast<const f32x4*>(pro1 + gc);
     }
   };
-  auto store_tiles = [&]() {
+  auto transform = [&](f32x4 v) {
+    f32x4 o;
+    if constexpr (PRO == PRO_NORM) {           // mineral/common/normalizers.py:65-68
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf((v[e] - pv0[e]) / pv1[e], p.clamp_lo), p.clamp_hi);
+    } else {                                   // LayerNorm affine + SiLU of the stored normalised activation
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = v[e] * pv0[e] + pv1[e];
+        o[e] = y * sigmoid_fast(y);
+      }
+    }
+    return o;
+  };
+  // prologue + zero fill + write to LDS of the tile that was loaded for reduction offset k0
+  auto store_tiles = [&](int k0) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < C::A_F4; ++i) {
-      int idx = tid + i * 256;
-      int r = idx / (C::CA / 4), c = (idx % (C::CA / 4)) * 4;
-      if (idx < C::RA * C::CA / 4) *reinterpret_cast<f32x4*>(As + r * SA + c) = ra[i];
+      const int r = rA0 + i * A_RSTEP;
+      if (r < C::RA) {
+        const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
+        const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
+        const bool ok = grow < ((LA == LAY_K) ? p.M : kend) && gcol < ((LA == LAY_K) ? kend : p.M);
+        f32x4 v = ra[i];
+        if constexpr (PRO_ON_A) v = transform(v);
+        *reinterpret_cast<f32x4*>(As + r * SA + cA) = ok ? v : zero;
+      }
     }
 #pragma unroll
     for (int i = 0; i < C::B_F4; ++i) {
-      int idx = tid + i * 256;
-      int r = idx / (C::CB / 4), c = (idx % (C::CB / 4)) * 4;
-      if (idx < C::RB * C::CB / 4) *reinterpret_cast<f32x4*>(Bs + r * SB + c) = rb[i];
+      const int r = rB0 + i * B_RSTEP;
+      if (r < C::RB) {
+        const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
+        const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
+        const bool ok = grow < ((LB == LAY_K) ? Nv : kend) && gcol < ((LB == LAY_K) ? kend : Nv);
+        f32x4 v = rb[i];
+        if constexpr (PRO_ON_B) v = transform(v);
+        *reinterpret_cast<f32x4*>(Bs + r * SB + cB) = ok ? v : zero;
+      }
     }
   };
 
   if (kbeg < kend) load_tiles(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();                 // previous tile fully consumed
-    store_tiles();
+    store_tiles(k0);
     __syncthreads();
-    if (k0 + BK < kend) load_tiles(k0 + BK);   // prefetch into registers while the MFMAs run
+    if (k0 + BK < kend) load_tiles(k0 + BK);   // raw prefetch into registers; consumed after the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];

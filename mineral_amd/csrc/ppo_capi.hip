@@ -237,11 +237,11 @@ extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flo
   return MRL_OK;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
   static int cls = [] {
     char nm[96];
-    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI);
+    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -251,7 +251,7 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO>), grid, dim3(256), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -262,25 +262,32 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
 }
 
 // full-row tiles, selected by the output width
-#define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, p, towers, s)                                                  \
-  do {                                                                                                             \
-    switch (N) {                                                                                                   \
-      case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;      \
-      case 256: launch_gemm<128, 256, BKBIG, 2, 2, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break; \
-      case 128: launch_gemm<128, 128, BKBIG, 2, 2, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break; \
-      case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
-      default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
-    }                                                                                                              \
+#define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, PRO, p, towers, s)                                                     \
+  do {                                                                                                                    \
+    switch (N) {                                                                                                          \
+      case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;        \
+      case 256: launch_gemm<128, 256, BKBIG, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+      case 128: launch_gemm<128, 128, BKBIG, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+      case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;     \
+      default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;     \
+    }                                                                                                                     \
   } while (0)
 
-static void launch_wgrad(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
+template <int PRO>
+static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
   dim3 grid(w.tiles_m, w.tiles_n * w.nsplit, towers);
   if (w.bm == 32)
-    launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+    launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
   else if (w.bn == 64)
-    launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+    launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
   else
-    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB>(p, grid, s);
+    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
+}
+
+static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers, hipStream_t s) {
+  if (pro == PRO_NORM) launch_wgrad_pro<PRO_NORM>(p, w, towers, s);
+  else if (pro == PRO_LNSILU) launch_wgrad_pro<PRO_LNSILU>(p, w, towers, s);
+  else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
@@ -304,11 +311,11 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.lda = in; p.ldb = in; p.ldo = u;
     p.M = (int)rows; p.N = u; p.K = in;
     p.Nt[0] = p.Nt[1] = u; p.Kt[0] = p.Kt[1] = in;
-    p.a_pro = (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU;
-    p.b_pro = PRO_NONE;
     p.clamp_lo = lo; p.clamp_hi = hi;
     p.ln_eps = net->ln_eps;
-    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, p, towers, s);
+    if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
+    else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
   }
 }
 
@@ -750,7 +757,6 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
   p.tw0 = tw0;
   p.lda = U; p.ldb = U;
   p.M = (int)N; p.N = 32; p.K = U;
-  p.a_pro = PRO_LNSILU;
   fill_heads_common(net, &p.h);
   p.h.noise = noise;
   p.h.act_out = buf->actions; p.h.mu = buf->mu; p.h.sigma = buf->sigma;
@@ -762,7 +768,7 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     p.h.vrms_mean = value_rms->mean; p.h.vrms_var = value_rms->var; p.h.vrms_eps = value_rms->eps;
     p.clamp_lo = value_rms->clamp_lo; p.clamp_hi = value_rms->clamp_hi;
   }
-  launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   MRL_CHECK_LAUNCH("mrl_policy_act");
   return MRL_OK;
 }
@@ -918,7 +924,6 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     }
     p.lda = U; p.ldb = U;
     p.M = (int)mb; p.N = 32; p.K = U;
-    p.a_pro = PRO_LNSILU;
     fill_heads_common(net, &p.h);
     p.h.actions = buf->actions + row0 * A;
     p.h.mu = buf->mu + row0 * A;
@@ -932,7 +937,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.inv_mb = 1.0f / (float)mb;
     p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
-    launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN>(p, dim3(hblocks, 1, 2), s);
+    launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, 2), s);
   }
   hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
                      hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
@@ -963,7 +968,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     const int kdim = (l == last) ? 32 : net->units[l + 1];
     p.lda = kdim; p.ldb = u; p.ldo = u;
     p.M = (int)mb; p.N = u; p.K = kdim;
-    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, p, 2, s);
+    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, PRO_NONE, p, 2, s);
   }
 
   // ---- backward: wgrad partial slabs -----------------------------------------------------------------------------
@@ -984,10 +989,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     }
     p.lda = gm; p.ldb = gn; p.ldo = gn;
     p.M = gm; p.N = gn; p.K = (int)mb;
-    p.b_pro = (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU;
     p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
     p.ksplit = wp.ksplit; p.n_tiles = wp.tiles_n;
-    launch_wgrad(p, wp, 2, s);
+    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU, 2, s);
   }
 
   // alignment gaps between tensors of the flat gradient are never produced by a kernel: start from zeros
