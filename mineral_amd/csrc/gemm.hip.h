@@ -92,6 +92,19 @@ __device__ __forceinline__ float sigmoid_fast(float y) {
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
 __device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + expf(-y)); }
 
+// Tile-relative buffer addressing for the epilogues: one descriptor per block tile (uniform), one 32-bit byte offset
+// per lane, and a compile-time scalar offset per element -- no per-element 64-bit address registers.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t tile_rsrc(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 // start of the last 4-float chunk that holds a valid column when `lim` columns are valid (lim >= 1)
 __device__ __forceinline__ int last_chunk(int lim) { return ((lim - 1) >> 2) << 2; }
 
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
   constexpr int A_RSTEP = 256 / (C::CA / 4), B_RSTEP = 256 / (C::CB / 4);
   const int cA = (tid % (C::CA / 4)) * 4, rA0 = tid / (C::CA / 4);
   const int cB = (tid % (C::CB / 4)) * 4, rB0 = tid / (C::CB / 4);
+  constexpr bool A_FULL = (C::RA * C::CA / 4) % 256 == 0, B_FULL = (C::RB * C::CB / 4) % 256 == 0;
   f32x4 ra[C::A_F4], rb[C::B_F4];
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};   // prologue vectors of this thread's column chunk
   if constexpr (PRO_ON_B) {   // wgrad: the feature index n0 + cB does not change along the reduction
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < C::A_F4; ++i) {
       const int r = rA0 + i * A_RSTEP;
-      if (r < C::RA) {
+      if (A_FULL || r < C::RA) {
         const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
         const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
         const int rlim = (LA == LAY_K) ? p.M : kend;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < C::B_F4; ++i) {
       const int r = rB0 + i * B_RSTEP;
-      if (r < C::RB) {
+      if (B_FULL || r < C::RB) {
         const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
         const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
         const int rlim = (LB == LAY_K) ? Nv : kend;
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < C::A_F4; ++i) {
       const int r = rA0 + i * A_RSTEP;
-      if (r < C::RA) {
+      if (A_FULL || r < C::RA) {
         const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
         const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
         const bool ok = grow < ((LA == LAY_K) ? p.M : kend) && gcol < ((LA == LAY_K) ? kend : p.M);
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < C::B_F4; ++i) {
       const int r = rB0 + i * B_RSTEP;
-      if (r < C::RB) {
+      if (B_FULL || r < C::RB) {
         const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
         const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
         const bool ok = grow < ((LB == LAY_K) ? Nv : kend) && gcol < ((LB == LAY_K) ? kend : Nv);
@@ -348,8 +362,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         }
       }
   } else if constexpr (EPI == EPI_LNFWD) {
+    // work on scalars from here on: element-wise updates of the 16-wide accumulator vectors cost whole-vector copies
+    float ea[TM][TN][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ea[im][in][r] = acc[im][in][r];
     // bias, two-pass LayerNorm statistics over the full row (BN == N), store xhat and rstd
-    constexpr int V = TM * 16;
     float* partA = lds;                 // [WGN][BM] row sums per wave column
     float* partB = lds + BM * WGN;      // [WGN][BM] sums of squared deviations
     const float* bias = p.bias[tw];
@@ -359,56 +380,55 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int im = 0; im < TM; ++im)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[im][in][r] += b;
+        for (int r = 0; r < 16; ++r) ea[im][in][r] += b;
     }
     const float invn = 1.0f / (float)BN;
-    const int own = (V == 32) ? l32 : (l32 >> 1);            // row slot whose total this lane ends up holding
-    const int own_row = wm * TM * 32 + (own >> 4) * 32 + (own & 3) + 8 * ((own & 15) >> 2) + 4 * h;
-    const bool owner = (V == 32) || ((l32 & 1) == 0);
-    {
-      float sv[V];
+    // after a 16-value halving reduction lane pair (2k, 2k+1) holds the total of value k of its half-wave
+    const int own = l32 >> 1;
+    const int own_row = wm * TM * 32 + (own & 3) + 8 * (own >> 2) + 4 * h;   // + im*32
+    const bool owner = (l32 & 1) == 0;
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
+    for (int im = 0; im < TM; ++im) {
+      float sv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float t = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        float t = 0.f;
 #pragma unroll
-          for (int in = 0; in < TN; ++in) t += acc[im][in][r];
-          sv[im * 16 + r] = t;
-        }
-      float tot = halving_sum32<V>(sv, l32);
-      if (owner) partA[wn * BM + own_row] = tot;
+        for (int in = 0; in < TN; ++in) t += ea[im][in][r];
+        sv[r] = t;
+      }
+      const float tot = halving_sum32<16>(sv, l32);
+      if (owner) partA[wn * BM + own_row + im * 32] = tot;
     }
     __syncthreads();
-    {
-      float qv[V];
 #pragma unroll
-      for (int im = 0; im < TM; ++im)
+    for (int im = 0; im < TM; ++im) {
+      float qv[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
-          f32x4 t = *reinterpret_cast<const f32x4*>(partA + base);
+      for (int g = 0; g < 4; ++g) {
+        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
+        f32x4 t = *reinterpret_cast<const f32x4*>(partA + base);
 #pragma unroll
-          for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partA + w * BM + base);
+        for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partA + w * BM + base);
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const float mean = t[rr] * invn;
-            float sq = 0.f;
+        for (int rr = 0; rr < 4; ++rr) {
+          const float mean = t[rr] * invn;
+          float sq = 0.f;
 #pragma unroll
-            for (int in = 0; in < TN; ++in) {
-              float d = acc[im][in][g * 4 + rr] - mean;
-              acc[im][in][g * 4 + rr] = d;
-              sq += d * d;
-            }
-            qv[im * 16 + g * 4 + rr] = sq;
+          for (int in = 0; in < TN; ++in) {
+            float d = ea[im][in][g * 4 + rr] - mean;
+            ea[im][in][g * 4 + rr] = d;
+            sq += d * d;
           }
+          qv[g * 4 + rr] = sq;
         }
-      float tot = halving_sum32<V>(qv, l32);
-      if (owner) partB[wn * BM + own_row] = tot;
+      }
+      const float tot = halving_sum32<16>(qv, l32);
+      if (owner) partB[wn * BM + own_row + im * 32] = tot;
     }
     __syncthreads();
-    // one per-lane base pointer; every element is then at a compile-time offset from it (ldo == BN here)
-    float* out_lane = p.out[tw] + (int64_t)(m0 + wm * TM * 32 + 4 * h) * BN + wn * TN * 32 + l32;
+    const rsrc_t out_rs = tile_rsrc(p.out[tw] + (int64_t)m0 * BN, BM * BN * 4);
+    const int lane_boff = (((wm * TM * 32 + 4 * h) * BN) + wn * TN * 32 + l32) * 4;
     float* rs = p.rstd[tw];
 #pragma unroll
     for (int im = 0; im < TM; ++im)
@@ -420,73 +440,99 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
         for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partB + w * BM + base);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
+          // rows >= M of the last block are written too: the activation workspace is padded to whole row tiles
           const float rstd = 1.0f / sqrtf(t[rr] * invn + p.ln_eps);
-          const int row = m0 + base + rr;
-          if (row < p.M) {
 #pragma unroll
-            for (int in = 0; in < TN; ++in) out_lane[(im * 32 + 8 * g + rr) * BN + in * 32] = acc[im][in][g * 4 + rr] * rstd;
-            if (wn == 0 && l32 == 0) rs[row] = rstd;
-          }
+          for (int in = 0; in < TN; ++in)
+            buf_store(ea[im][in][g * 4 + rr] * rstd, out_rs, lane_boff, ((im * 32 + 8 * g + rr) * BN + in * 32) * 4);
+          if (wn == 0 && l32 == 0) rs[m0 + base + rr] = rstd;
         }
       }
   } else if constexpr (EPI == EPI_LNBWD) {
+    // work on scalars from here on: element-wise updates of the 16-wide accumulator vectors cost whole-vector copies
+    float ea[TM][TN][16];
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ea[im][in][r] = acc[im][in][r];
     // acc = d loss / d h with h = silu(y), y = xhat*gamma + beta, xhat = LayerNorm-normalised z.
     // dy = dh * silu'(y); dxhat = dy*gamma; dz = rstd * (dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)).
-    constexpr int V = TM * 16;
     float* part1 = lds;                        // [WGN][BM]  sum dxhat
     float* part2 = lds + BM * WGN;             // [WGN][BM]  sum dxhat*xhat
     float* cred = lds + 2 * BM * WGN;          // [WGM][3][BN] column partials (dgamma, dbeta, dbias)
-    const int64_t lane_off = (int64_t)(m0 + wm * TM * 32 + 4 * h) * BN + wn * TN * 32 + l32;
-    const float* xh_lane = p.xhat[tw] + lane_off;   // element (im, r, in) sits at a compile-time offset from here
-    float* out_lane = p.out[tw] + lane_off;
+    const rsrc_t xh_rs = tile_rsrc(p.xhat[tw] + (int64_t)m0 * BN, BM * BN * 4);
+    const rsrc_t out_rs = tile_rsrc(p.out[tw] + (int64_t)m0 * BN, BM * BN * 4);
+    const int lane_boff = (((wm * TM * 32 + 4 * h) * BN) + wn * TN * 32 + l32) * 4;
     const float* gam = p.gamma[tw];
     const float* bet = p.beta[tw];
     const float invn = 1.0f / (float)BN;
-    const int own = (V == 32) ? l32 : (l32 >> 1);
-    const int own_row = wm * TM * 32 + (own >> 4) * 32 + (own & 3) + 8 * ((own & 15) >> 2) + 4 * h;
-    const bool owner = (V == 32) || ((l32 & 1) == 0);
-    {
-      float c1[V], c2[V];
+    const int own = l32 >> 1;
+    const int own_row = wm * TM * 32 + (own & 3) + 8 * (own >> 2) + 4 * h;   // + im*32
+    const bool owner = (l32 & 1) == 0;
+    float gv[TN], bv[TN], sg[TN], sb[TN];
 #pragma unroll
-      for (int v = 0; v < V; ++v) c1[v] = c2[v] = 0.f;
+    for (int in = 0; in < TN; ++in) {
+      gv[in] = gam[n0 + colof(in)];
+      bv[in] = bet[n0 + colof(in)];
+      sg[in] = sb[in] = 0.f;
+    }
+    // pass 1, software-pipelined by hand: batch b = (im, in, half) covers 8 elements; the loads of batch b+1 are in
+    // flight while batch b is computed.  Small batches keep the per-element temporaries within the register budget.
+    constexpr int NB1 = TM * TN * 2;
+    auto x_off1 = [&](int b, int e) {
+      const int im = b / (TN * 2), in = (b / 2) % TN, r = (b & 1) * 8 + e;
+      return ((im * 32 + (r & 3) + 8 * (r >> 2)) * BN + in * 32) * 4;
+    };
+    float xb[2][8];
 #pragma unroll
-      for (int in = 0; in < TN; ++in) {
-        const int col = n0 + colof(in);
-        const float g = gam[col], b = bet[col];
-        float sg = 0.f, sb = 0.f;
+    for (int e = 0; e < 8; ++e) xb[0][e] = buf_load(xh_rs, lane_boff, x_off1(0, e));
+    float c1[16], c2[16];
 #pragma unroll
-        for (int im = 0; im < TM; ++im)
+    for (int b = 0; b < NB1; ++b) {
+      const int im = b / (TN * 2), in = (b / 2) % TN, hf = b & 1;
+      if (in == 0 && hf == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + rowof(im, r);
-            float x = 0.f, dxh = 0.f;
-            if (row < p.M) {
-              x = xh_lane[(im * 32 + (r & 3) + 8 * (r >> 2)) * BN + in * 32];
-              const float y = x * g + b;
-              const float sgm = sigmoid_fast(y);
-              const float dy = acc[im][in][r] * (sgm * (1.0f + y * (1.0f - sgm)));
-              sg += dy * x;
-              sb += dy;
-              dxh = dy * g;
-            }
-            acc[im][in][r] = dxh;
-            c1[im * 16 + r] += dxh;
-            c2[im * 16 + r] += dxh * x;
-            if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 xhat loads in flight: register pressure
-          }
-        sg += __shfl_xor(sg, 32);
-        sb += __shfl_xor(sb, 32);
-        if (h == 0) {
-          cred[(wm * 3 + 0) * BN + colof(in)] = sg;
-          cred[(wm * 3 + 1) * BN + colof(in)] = sb;
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the next column's loads from being hoisted (register pressure)
+        for (int r = 0; r < 16; ++r) c1[r] = c2[r] = 0.f;
       }
-      float t1 = halving_sum32<V>(c1, l32);
-      float t2 = halving_sum32<V>(c2, l32);
-      if (owner) {
-        part1[wn * BM + own_row] = t1;
-        part2[wn * BM + own_row] = t2;
+      if (b + 1 < NB1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xb[(b + 1) & 1][e] = buf_load(xh_rs, lane_boff, x_off1(b + 1, e));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // no row guard: rows >= M carry dh == 0 (their A rows were zero-filled) and the workspace is padded
+        const int r = hf * 8 + e;
+        const float x = xb[b & 1][e];
+        const float y = x * gv[in] + bv[in];
+        const float sgm = sigmoid_fast(y);
+        const float dy = ea[im][in][r] * (sgm * (1.0f + y * (1.0f - sgm)));
+        sg[in] += dy * x;
+        sb[in] += dy;
+        const float dxh = dy * gv[in];
+        ea[im][in][r] = dxh;
+        c1[r] += dxh;
+        c2[r] += dxh * x;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (in == TN - 1 && hf == 1) {
+        const float t1 = halving_sum32<16>(c1, l32);
+        const float t2 = halving_sum32<16>(c2, l32);
+        if (owner) {
+          part1[wn * BM + own_row + im * 32] = t1;
+          part2[wn * BM + own_row + im * 32] = t2;
+        }
+      }
+    }
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const float a = sg[in] + __shfl_xor(sg[in], 32);
+      const float b = sb[in] + __shfl_xor(sb[in], 32);
+      if (h == 0) {
+        cred[(wm * 3 + 0) * BN + colof(in)] = a;
+        cred[(wm * 3 + 1) * BN + colof(in)] = b;
       }
     }
     __syncthreads();
@@ -494,35 +540,47 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
     float cz[TN];
 #pragma unroll
     for (int in = 0; in < TN; ++in) cz[in] = 0.f;
+    // pass 2, same pipelining: group q = (im, g) is 4 rows x TN columns; loads of group q+1 fly during group q
+    constexpr int NG2 = TM * 4;
+    float xs[2][4][TN];
 #pragma unroll
-    for (int im = 0; im < TM; ++im)
+    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
-        f32x4 t1 = *reinterpret_cast<const f32x4*>(part1 + base);
-        f32x4 t2 = *reinterpret_cast<const f32x4*>(part2 + base);
+      for (int in = 0; in < TN; ++in) xs[0][rr][in] = buf_load(xh_rs, lane_boff, (rr * BN + in * 32) * 4);
 #pragma unroll
-        for (int w = 1; w < WGN; ++w) {
-          t1 += *reinterpret_cast<const f32x4*>(part1 + w * BM + base);
-          t2 += *reinterpret_cast<const f32x4*>(part2 + w * BM + base);
-        }
+    for (int q = 0; q < NG2; ++q) {
+      const int im = q / 4, g = q % 4;
+      const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
+      f32x4 t1 = *reinterpret_cast<const f32x4*>(part1 + base);
+      f32x4 t2 = *reinterpret_cast<const f32x4*>(part2 + base);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = m0 + base + rr;
-          if (row < p.M) {
-            const float rstd = rs[row];
-            const float m1 = t1[rr] * invn, m2 = t2[rr] * invn;
-#pragma unroll
-            for (int in = 0; in < TN; ++in) {
-              const float x = xh_lane[(im * 32 + 8 * g + rr) * BN + in * 32];
-              const float dz = rstd * (acc[im][in][g * 4 + rr] - m1 - x * m2);
-              out_lane[(im * 32 + 8 * g + rr) * BN + in * 32] = dz;
-              cz[in] += dz;
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int w = 1; w < WGN; ++w) {
+        t1 += *reinterpret_cast<const f32x4*>(part1 + w * BM + base);
+        t2 += *reinterpret_cast<const f32x4*>(part2 + w * BM + base);
       }
+      const f32x4 rs4 = *reinterpret_cast<const f32x4*>(rs + m0 + base);
+      if (q + 1 < NG2) {
+        const int im2 = (q + 1) / 4, g2 = (q + 1) % 4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            xs[(q + 1) & 1][rr][in] = buf_load(xh_rs, lane_boff, ((im2 * 32 + 8 * g2 + rr) * BN + in * 32) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float rstd = rs4[rr];
+        const float m1 = t1[rr] * invn, m2 = t2[rr] * invn;
+#pragma unroll
+        for (int in = 0; in < TN; ++in) {
+          const float dz = rstd * (ea[im][in][g * 4 + rr] - m1 - xs[q & 1][rr][in] * m2);
+          buf_store(dz, out_rs, lane_boff, ((im * 32 + 8 * g + rr) * BN + in * 32) * 4);
+          cz[in] += dz;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
       float z = cz[in] + __shfl_xor(cz[in], 32);

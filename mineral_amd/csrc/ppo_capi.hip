@@ -137,12 +137,14 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   ParamLayout L;
   param_layout(net, &L);
   int U = net->units[net->n_layers - 1];
+  // activation tensors are padded to whole 128-row tiles: the LayerNorm epilogues read and write full tiles
+  const int64_t rows_pad = cdiv(rows, 128) * 128;
   for (int tw = 0; tw < 2; ++tw) {
     for (int l = 0; l < net->n_layers; ++l) {
       int u = net->units[l];
-      w->xhat[tw][l] = o; o = align64(o + rows * u);
-      w->rstd[tw][l] = o; o = align64(o + rows);
-      w->dz[tw][l] = o; o = align64(o + rows * u);
+      w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
+      w->rstd[tw][l] = o; o = align64(o + rows_pad);
+      w->dz[tw][l] = o; o = align64(o + rows_pad * u);
       w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
