@@ -12,6 +12,10 @@
 
 using namespace mrl;
 
+#ifndef BWD512_BM
+#define BWD512_BM 32
+#endif
+
 static thread_local char g_err[512] = "";
 
 #define MRL_FAIL(code, ...)                      \
@@ -101,6 +105,10 @@ extern "C" int mrl_param_offsets(const mrl_net* net, int64_t* offs, int32_t* n) 
 }
 
 static inline int fwd_bm(int n) { return n == 512 ? 64 : 128; }   // rows per block of the full-row (LayerNorm) tiles
+static inline int bwd_bm(int n) { return n == 512 ? BWD512_BM : 128; }
+// wide layers take the streaming LayerNorm backward: rows per block of that kernel
+static inline bool ln_bwd_streamed(int n) { return n >= 256; }
+static inline int ln_bwd_rows(int64_t rows) { int64_t r = cdiv(rows, 512); return (int)(r < 4 ? 4 : cdiv(r, 4) * 4); }
 
 struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 
@@ -145,7 +153,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
       w->rstd[tw][l] = o; o = align64(o + rows_pad);
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
-      w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));
+      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, bwd_bm(u));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
@@ -585,20 +593,130 @@ __global__ void rms_normalize_kernel(const double* __restrict__ mean, const doub
   }
 }
 
+// LayerNorm + SiLU backward as a streaming pass for the wide layers (N = 256 / 512), one wave per row:
+//   dh (in `dz`, overwritten) -> dy = dh*silu'(y), y = xhat*gamma+beta -> dxhat = dy*gamma ->
+//   dz = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)); column partials dgamma, dbeta, dbias per block.
+// Reads 2N floats and writes N floats per row, fully coalesced (16 B per lane).  grid = (blocks, towers).
+struct LnBwdArgs {
+  float* dz[2];
+  const float* xhat[2];
+  const float* rstd[2];
+  const float* gamma[2];
+  const float* beta[2];
+  float* colpart[2];   // [gridDim.x][3][N]
+  int M, rows_per_block;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+  constexpr int C = N / 256;                 // float4 chunks per lane
+  __shared__ f32x4 red[3][4][N / 4];
+  const int tw = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* __restrict__ dz = a.dz[tw];
+  const float* __restrict__ xh = a.xhat[tw];
+  const float* __restrict__ rs = a.rstd[tw];
+  f32x4 g[C], b[C], cg[C], cb[C], cz[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    g[c] = *reinterpret_cast<const f32x4*>(a.gamma[tw] + 4 * (lane + 64 * c));
+    b[c] = *reinterpret_cast<const f32x4*>(a.beta[tw] + 4 * (lane + 64 * c));
+    cg[c] = cb[c] = cz[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r1 = min(a.M, r0 + a.rows_per_block);
+  const float invn = 1.0f / (float)N;
+  for (int row = r0 + wave; row < r1; row += 4) {
+    f32x4 x[C], d[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      x[c] = *reinterpret_cast<const f32x4*>(xh + (int64_t)row * N + 4 * (lane + 64 * c));
+      d[c] = *reinterpret_cast<const f32x4*>(dz + (int64_t)row * N + 4 * (lane + 64 * c));
+    }
+    const float rstd = rs[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = x[c][e] * g[c][e] + b[c][e];
+        const float sg = sigmoid_fast(y);
+        const float dy = d[c][e] * (sg * (1.0f + y * (1.0f - sg)));
+        cg[c][e] += dy * x[c][e];
+        cb[c][e] += dy;
+        const float dxh = dy * g[c][e];
+        d[c][e] = dxh;
+        s1 += dxh;
+        s2 += dxh * x[c][e];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 * invn, m2 = s2 * invn;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = rstd * (d[c][e] - m1 - x[c][e] * m2);
+        d[c][e] = z;
+        cz[c][e] += z;
+      }
+      *reinterpret_cast<f32x4*>(dz + (int64_t)row * N + 4 * (lane + 64 * c)) = d[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    red[0][wave][lane + 64 * c] = cg[c];
+    red[1][wave][lane + 64 * c] = cb[c];
+    red[2][wave][lane + 64 * c] = cz[c];
+  }
+  __syncthreads();
+  float* cp = a.colpart[tw] + (int64_t)blockIdx.x * 3 * N;
+  for (int i = threadIdx.x; i < 3 * N / 4; i += 256) {
+    const int qn = i / (N / 4), j = i % (N / 4);
+    const f32x4 t = (red[qn][0][j] + red[qn][1][j]) + (red[qn][2][j] + red[qn][3][j]);
+    *reinterpret_cast<f32x4*>(cp + 4 * i) = t;
+  }
+}
+
 // Sum `nslabs` partial slabs into the flat gradient.  One descriptor per gradient tensor; grid.y = descriptor.
 struct ReduceDesc { const float* src; float* dst; int64_t count; int64_t stride; int nslabs; };
 #define MRL_MAX_RDESC 48
 struct ReduceTable { ReduceDesc d[MRL_MAX_RDESC]; int n; };
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
+  // block = 16 column chunks (of 4 floats) x 16 slab lanes: lane q sums slabs q, q+16, ... and the 16 partial sums are
+  // combined in a fixed order through LDS, so the result does not depend on scheduling.  Short dependent chains:
+  // the deepest descriptors have a few hundred slabs.
+  __shared__ f32x4 red[16][16];
   const ReduceDesc d = tab.d[blockIdx.y];
+  const int cx = threadIdx.x & 15, q = threadIdx.x >> 4;
   if ((d.count & 3) == 0 && (d.stride & 3) == 0) {
     const int64_t n4 = d.count >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k = 0; k < d.nslabs; ++k) s += *reinterpret_cast<const f32x4*>(d.src + k * d.stride + 4 * i);
-      *reinterpret_cast<f32x4*>(d.dst + 4 * i) = s;
+    for (int64_t c0 = (int64_t)blockIdx.x * 16; c0 < n4; c0 += (int64_t)gridDim.x * 16) {
+      const int64_t i = c0 + cx;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      if (i < n4) {
+        const float* src = d.src + 4 * i;
+        int k = q;
+        for (; k + 48 < d.nslabs; k += 64) {
+          s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * d.stride);
+          s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 16) * d.stride);
+          s2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 32) * d.stride);
+          s3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 48) * d.stride);
+        }
+        for (; k < d.nslabs; k += 16) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * d.stride);
+      }
+      red[q][cx] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (q == 0 && i < n4) {
+        f32x4 t = red[0][cx];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += red[w][cx];
+        *reinterpret_cast<f32x4*>(d.dst + 4 * i) = t;
+      }
+      __syncthreads();
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * 256) {
@@ -970,7 +1088,22 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     const int kdim = (l == last) ? 32 : net->units[l + 1];
     p.lda = kdim; p.ldb = u; p.ldo = u;
     p.M = (int)mb; p.N = u; p.K = kdim;
-    MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, PRO_NONE, p, 2, s);
+    if (ln_bwd_streamed(u)) {
+      // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
+      p.ksplit = kdim; p.n_tiles = u / 128;
+      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3((unsigned)cdiv(mb, 128), u / 128, 2), s);
+      LnBwdArgs a;
+      for (int tw = 0; tw < 2; ++tw) {
+        a.dz[tw] = ws + W.dz[tw][l]; a.xhat[tw] = ws + W.xhat[tw][l]; a.rstd[tw] = ws + W.rstd[tw][l];
+        a.gamma[tw] = params + L.g[tw][l]; a.beta[tw] = params + L.be[tw][l]; a.colpart[tw] = ws + W.colpart[tw][l];
+      }
+      a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
+      dim3 grid(W.rowblocks[l], 2);
+      if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
+    } else {
+      MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, PRO_NONE, p, 2, s);
+    }
   }
 
   // ---- backward: wgrad partial slabs -----------------------------------------------------------------------------
@@ -1022,8 +1155,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     add(ws + W.headb_part + tw * 32, L.bh[tw], hn, 64, hblocks);
   }
   {
-    int gx = (int)cdiv(maxcount, 1024);
-    if (gx > 256) gx = 256;
+    int gx = (int)cdiv(maxcount, 64);
+    if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
   }
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
