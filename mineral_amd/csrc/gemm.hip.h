@@ -175,11 +175,12 @@ struct GemmCfg {
 
 // PRO: prologue applied while staging — to operand A in the forward kernels (LA == LAY_K), to operand B in wgrad
 // (EPI_SLAB).  The feature index of an element is its column in the stored matrix in both cases.
-// blocks per CU asked of the register allocator: 3 when the accumulators take at most 64 registers per lane
-constexpr int gemm_min_waves(int bm, int bn) { return (bm * bn / 256 <= 64) ? 3 : 2; }
+// blocks per CU asked of the register allocator: 3 for the plain-store kernels whose accumulators take at most 64
+// registers per lane (the LayerNorm / heads epilogues need the larger budget)
+constexpr int gemm_min_waves(int bm, int bn, int epi) { return (epi == EPI_SLAB && bm * bn / 256 <= 64) ? 3 : 2; }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO>
-__global__ __launch_bounds__(256, gemm_min_waves(BM, BN)) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
   constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
   constexpr bool PRO_ON_A = (PRO != PRO_NONE) && (EPI != EPI_SLAB);

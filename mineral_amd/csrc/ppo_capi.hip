@@ -1152,7 +1152,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     }
     const int hn = (tw == 0) ? 2 * A : 1;
     add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
-    add(ws + W.headb_part + tw * 32, L.bh[tw], hn, 64, hblocks);
+    // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
+    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(hn), 64, hblocks);
   }
   {
     int gx = (int)cdiv(maxcount, 64);
