@@ -67,8 +67,12 @@ struct GemmP {
   const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU: gamma[f]
   const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU: beta[f]
   float clamp_lo, clamp_hi;
-  int ksplit;                  // EPI_SLAB: reduction rows per split (gridDim.y = n_tiles * n_split)
-  int n_tiles;                 // EPI_SLAB: number of N tiles
+  // EPI_SLAB launches use a 1-D grid of 8*ceil(groups/8)*group_size blocks.  A group is the set of tiles that read the
+  // same operand rows (dgrad: the N tiles of one row block; wgrad: all tiles of one batch split); its blocks are given
+  // ids that differ by 8 so that they land on one XCD and share its L2 (placement is a speed matter only).
+  int ksplit;                  // reduction rows per split
+  int m_tiles, n_tiles;        // tile grid of the output
+  int n_groups, group_mode;    // group_mode 0: group = row tile (dgrad), 1: group = split (wgrad)
   // EPI_LNFWD: out = xhat [M][N], rstd [M], bias [N]
   // EPI_LNBWD: out = dz [M][N]; xhat/rstd/gamma/beta of the layer being differentiated; colpart slab
   // EPI_SLAB : out = slab [n_split][M][N]
@@ -179,7 +183,7 @@ struct GemmCfg {
 // registers per lane (the LayerNorm / heads epilogues need the larger budget)
 constexpr int gemm_min_waves(int bm, int bn, int epi) { return (epi == EPI_SLAB && bm * bn / 256 <= 64) ? 3 : 2; }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO>
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF>
 __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
   constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
@@ -188,9 +192,9 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
   static_assert(!PRO_ON_A || LA == LAY_K, "forward prologue expects a k-contiguous A");
   static_assert(!PRO_ON_B || LB == LAY_R, "wgrad prologue expects a row-reduction B");
   static_assert(256 % (C::CA / 4) == 0 && 256 % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
-  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  float* As = lds;
-  float* Bs = lds + C::RA * SA;
+  static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
+  constexpr int LDS_ALL = (NBUF * C::LDS_TILES > C::LDS_EPI) ? NBUF * C::LDS_TILES : C::LDS_EPI;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -198,14 +202,24 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
   const int wm = wave / WGN, wn = wave % WGN;
   const int tw = blockIdx.z;                 // index into the per-tower pointer arrays
   const int Nv = p.Nt[tw] ? p.Nt[tw] : p.N;  // valid output columns / reduction length of this tower
-  const int m0 = blockIdx.x * BM;
-  int n0, kbeg = 0, kend = p.Kt[tw] ? p.Kt[tw] : p.K, split = 0;
+  int m0, n0, kbeg = 0, kend = p.Kt[tw] ? p.Kt[tw] : p.K, split = 0;
   if (EPI == EPI_SLAB) {
-    n0 = (blockIdx.y % p.n_tiles) * BN;
-    split = blockIdx.y / p.n_tiles;
+    const int gsz = p.group_mode ? p.m_tiles * p.n_tiles : p.n_tiles;
+    const int lin = blockIdx.x, t = lin >> 3, j = t % gsz;
+    const int grp = (t / gsz) * 8 + (lin & 7);
+    if (grp >= p.n_groups) return;           // padding blocks of the last octet of groups
+    if (p.group_mode) {
+      split = grp;
+      m0 = (j % p.m_tiles) * BM;
+      n0 = (j / p.m_tiles) * BN;
+    } else {
+      m0 = grp * BM;
+      n0 = j * BN;
+    }
     kbeg = split * p.ksplit;
     kend = min(kend, kbeg + p.ksplit);
   } else {
+    m0 = blockIdx.x * BM;
     n0 = blockIdx.y * BN;
   }
   const float* __restrict__ Ag = p.A[tw];
@@ -280,8 +294,10 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     return o;
   };
   // prologue + zero fill + write to LDS of the tile that was loaded for reduction offset k0
-  auto store_tiles = [&](int k0) {
+  auto store_tiles = [&](int k0, int buf) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float* As = lds + buf * C::LDS_TILES;
+    float* Bs = As + C::RA * SA;
 #pragma unroll
     for (int i = 0; i < C::A_F4; ++i) {
       const int r = rA0 + i * A_RSTEP;
@@ -308,12 +324,9 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     }
   };
 
-  if (kbeg < kend) load_tiles(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();                 // previous tile fully consumed
-    store_tiles(k0);
-    __syncthreads();
-    if (k0 + BK < kend) load_tiles(k0 + BK);   // raw prefetch into registers; consumed after the MFMAs below
+  auto mfma_tile = [&](int buf) {
+    const float* As = lds + buf * C::LDS_TILES;
+    const float* Bs = As + C::RA * SA;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];
@@ -344,6 +357,34 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
 #pragma unroll
           for (int in = 0; in < TN; ++in)
             acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+    }
+  };
+
+  if constexpr (NBUF == 1) {
+    if (kbeg < kend) load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      __syncthreads();                 // previous tile fully consumed
+      store_tiles(k0, 0);
+      __syncthreads();
+      if (k0 + BK < kend) load_tiles(k0 + BK);   // raw prefetch into registers; consumed after the MFMAs below
+      mfma_tile(0);
+    }
+  } else {
+    // double-buffered: tile s+1 goes from registers into the other LDS buffer and tile s+2 from memory into registers
+    // while the MFMAs of tile s run; one barrier per reduction step
+    const int nsteps = (kend - kbeg + BK - 1) / BK;
+    if (nsteps > 0) {
+      load_tiles(kbeg);
+      store_tiles(kbeg, 0);
+    }
+    if (nsteps > 1) load_tiles(kbeg + BK);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int k0 = kbeg + st * BK, cur = st & 1;
+      if (st + 1 < nsteps) store_tiles(k0 + BK, cur ^ 1);
+      if (st + 2 < nsteps) load_tiles(k0 + 2 * BK);
+      mfma_tile(cur);
+      __syncthreads();
     }
   }
   __syncthreads();   // LDS is reused as reduction scratch below

@@ -247,11 +247,11 @@ extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flo
   return MRL_OK;
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO>
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
   static int cls = [] {
     char nm[96];
-    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO);
+    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -261,7 +261,7 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -275,17 +275,19 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
 #define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, PRO, p, towers, s)                                                     \
   do {                                                                                                                    \
     switch (N) {                                                                                                          \
-      case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;        \
-      case 256: launch_gemm<128, 256, BKBIG, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+      case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI, PRO, 1>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;        \
+      case 256: launch_gemm<128, 256, 16, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
       case 128: launch_gemm<128, 128, BKBIG, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
       case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;     \
       default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;     \
     }                                                                                                                     \
   } while (0)
 
+static inline unsigned slab_grid(int n_groups, int group_size) { return (unsigned)(cdiv(n_groups, 8) * 8 * group_size); }
+
 template <int PRO>
 static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
-  dim3 grid(w.tiles_m, w.tiles_n * w.nsplit, towers);
+  dim3 grid(slab_grid(w.nsplit, w.tiles_m * w.tiles_n), 1, towers);
   if (w.bm == 32)
     launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
   else if (w.bn == 64)
@@ -1090,8 +1092,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.M = (int)mb; p.N = u; p.K = kdim;
     if (ln_bwd_streamed(u)) {
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
-      p.ksplit = kdim; p.n_tiles = u / 128;
-      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3((unsigned)cdiv(mb, 128), u / 128, 2), s);
+      p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
+      p.n_groups = p.m_tiles; p.group_mode = 0;
+      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
       LnBwdArgs a;
       for (int tw = 0; tw < 2; ++tw) {
         a.dz[tw] = ws + W.dz[tw][l]; a.xhat[tw] = ws + W.xhat[tw][l]; a.rstd[tw] = ws + W.rstd[tw][l];
@@ -1125,7 +1128,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.lda = gm; p.ldb = gn; p.ldo = gn;
     p.M = gm; p.N = gn; p.K = (int)mb;
     p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
-    p.ksplit = wp.ksplit; p.n_tiles = wp.tiles_n;
+    p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
+    p.n_groups = wp.nsplit; p.group_mode = 1;
     launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU, 2, s);
   }
 
