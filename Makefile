@@ -14,6 +14,10 @@ $(LIB): $(SRC) $(HDR)
 resources: $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage $(SRC) -o /tmp/_mrl_res.so 2>&1 | python3 tools/resource_table.py
 
+# instrumented diagnostic build (cycle stamps inside the GEMM main loop), see tools/ktrace_run.py
+ktrace: $(SRC) $(HDR)
+	mkdir -p tools/bin && $(HIPCC) $(HIPFLAGS) -DMRL_KTRACE $(SRC) -o tools/bin/libmineral_ppo_ktrace.so
+
 clean:
 	rm -f $(LIB)
-.PHONY: all resources clean
+.PHONY: all resources ktrace clean

@@ -86,7 +86,31 @@ struct GemmP {
   float* colpart[2];           // LNBWD: [gridDim.x][3][N]  (dgamma, dbeta, dbias partial column sums)
   float ln_eps;
   HeadsP h;
+#ifdef MRL_KTRACE
+  int ktrace;                  // instrumented diagnostic build only: 1 + z = block 8 of tower z records cycle stamps
+#endif
 };
+
+#ifdef MRL_KTRACE
+// Instrumented diagnostic build (tools/ktrace_run.py): cycle-counter stamps of the four waves of one block.
+constexpr int KTRACE_SLOTS = 1024;
+__device__ unsigned long long g_ktrace[4][KTRACE_SLOTS];
+constexpr int KTRACE_BLOCKS = 8192;
+__device__ unsigned long long g_kblock[KTRACE_BLOCKS][2];   // 100 MHz clock at entry / exit of every block
+#define MRL_KB(which)                                                                                    \
+  do {                                                                                                   \
+    const unsigned kb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
+    if (p.ktrace && threadIdx.x == 0 && kb_ < KTRACE_BLOCKS) g_kblock[kb_][which] = wall_clock64();       \
+  } while (0)
+#define MRL_KT(slot)                                                                                     \
+  do {                                                                                                   \
+    if (p.ktrace && blockIdx.x == 8 && blockIdx.z == p.ktrace - 1 && (threadIdx.x & 63) == 0 && (slot) < KTRACE_SLOTS) \
+      g_ktrace[threadIdx.x >> 6][(slot)] = __builtin_readcyclecounter();                                 \
+  } while (0)
+#else
+#define MRL_KT(slot) do { } while (0)
+#define MRL_KB(which) do { } while (0)
+#endif
 
 // fast sigmoid on the hardware exp2 / rcp (about 1 ulp each); used where the result feeds fp32 GEMM operands
 __device__ __forceinline__ float sigmoid_fast(float y) {
@@ -196,6 +220,8 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
   constexpr int LDS_ALL = (NBUF * C::LDS_TILES > C::LDS_EPI) ? NBUF * C::LDS_TILES : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
 
+  MRL_KT(1000);
+  MRL_KB(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, h = lane >> 5;
@@ -203,6 +229,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
   const int tw = blockIdx.z;                 // index into the per-tower pointer arrays
   const int Nv = p.Nt[tw] ? p.Nt[tw] : p.N;  // valid output columns / reduction length of this tower
   int m0, n0, kbeg = 0, kend = p.Kt[tw] ? p.Kt[tw] : p.K, split = 0;
+  const int kend_full = kend;
   if (EPI == EPI_SLAB) {
     const int gsz = p.group_mode ? p.m_tiles * p.n_tiles : p.n_tiles;
     const int lin = blockIdx.x, t = lin >> 3, j = t % gsz;
@@ -248,36 +275,79 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     pv1 = *reinterpret_cast<const f32x4*>(pro1 + gc);
   }
 
-  // Loads are unconditional (addresses clamped into the matrix) so that they issue back to back; out-of-range
-  // elements are zeroed when the tile is written to LDS.
+  // Operand tiles are read through one buffer descriptor per operand whose base is this block's first element: a
+  // lane's byte offset inside the tile never changes (one register per staging unit, clamped into the matrix along
+  // the dimension that does not move), and the reduction offset of the step is a scalar.  Reads past the end of the
+  // matrix return zeros instead of faulting, so the loads are unconditional -- also for the tiles prefetched past the
+  // end of the reduction; what lies outside the valid rows / columns is zeroed when the tile is written to LDS.
+  // A staging unit is one 16-byte chunk per thread: units 0 .. A_F4-1 belong to the A tile, the rest to the B tile.
+  constexpr int NSTAGE = C::A_F4 + C::B_F4;
+  const int kfull = kend_full;   // reduction length of the whole matrix (the rows that exist in a LAY_R operand)
+  auto operand_rsrc = [&](const float* base, int lay, int64_t ld, int fixed0, int fixed_n) {
+    // lay LAY_K: rows fixed0.. of fixed_n rows, columns = reduction;  LAY_R: rows = reduction, columns of fixed_n
+    const int64_t origin = (lay == LAY_K) ? (int64_t)fixed0 * ld + kbeg : (int64_t)kbeg * ld;
+    const int64_t extent = (lay == LAY_K) ? (int64_t)(fixed_n - 1) * ld + kfull : (int64_t)(kfull - 1) * ld + fixed_n;
+    // a row whose length is not a multiple of 4 ends inside a 4-float chunk: the chunk's tail must stay readable
+    const int ncols = (lay == LAY_K) ? kfull : fixed_n;
+    int64_t bytes = (extent - origin + ((4 - (ncols & 3)) & 3)) * 4;
+    bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + origin), 0, (int)(unsigned)bytes, 0x00020000);
+  };
+  const rsrc_t rsA = operand_rsrc(Ag, LA, p.lda, m0, p.M);
+  const rsrc_t rsB = operand_rsrc(Bg, LB, p.ldb, n0, Nv);
+  int voffA[C::A_F4], voffB[C::B_F4];
+  bool inA[C::A_F4], inB[C::B_F4];   // the part of the validity test that does not depend on the reduction offset
+#pragma unroll
+  for (int i = 0; i < C::A_F4; ++i) {
+    const int r = rA0 + i * A_RSTEP;
+    if (LA == LAY_K) {
+      voffA[i] = (int)(((int64_t)(min(m0 + r, p.M - 1) - m0) * p.lda + cA) * 4);
+      inA[i] = m0 + r < p.M;
+    } else {
+      voffA[i] = (int)(((int64_t)r * p.lda + min(m0 + cA, last_chunk(p.M))) * 4);
+      inA[i] = m0 + cA < p.M;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < C::B_F4; ++i) {
+    const int r = rB0 + i * B_RSTEP;
+    if (LB == LAY_K) {
+      voffB[i] = (int)(((int64_t)(min(n0 + r, Nv - 1) - n0) * p.ldb + cB) * 4);
+      inB[i] = n0 + r < Nv;
+    } else {
+      voffB[i] = (int)(((int64_t)r * p.ldb + min(n0 + cB, last_chunk(Nv))) * 4);
+      inB[i] = n0 + cB < Nv;
+    }
+  }
+  const int kstepA = (LA == LAY_K) ? 4 : (int)(p.lda * 4), kstepB = (LB == LAY_K) ? 4 : (int)(p.ldb * 4);   // bytes per reduction index
+  rsrc_t rsP0, rsP1;
+  if constexpr (PRO_ON_A) {   // forward prologue vectors follow the reduction offset of the A tile
+    const int bytes = (kfull - kbeg) * 4;
+    rsP0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pro0 + kbeg), 0, bytes, 0x00020000);
+    rsP1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pro1 + kbeg), 0, bytes, 0x00020000);
+  }
+  auto load16 = [](rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  };
+  auto load_unit = [&](int u, int k0) {
+    if (u < C::A_F4) {
+      const int i = u;
+      if (A_FULL || rA0 + i * A_RSTEP < C::RA) ra[i] = load16(rsA, voffA[i], (k0 - kbeg) * kstepA);
+    } else {
+      const int i = u - C::A_F4;
+      if (B_FULL || rB0 + i * B_RSTEP < C::RB) rb[i] = load16(rsB, voffB[i], (k0 - kbeg) * kstepB);
+    }
+  };
+  auto load_pro = [&](int k0) {
+    if constexpr (PRO_ON_A) {
+      pv0 = load16(rsP0, cA * 4, (k0 - kbeg) * 4);
+      pv1 = load16(rsP1, cA * 4, (k0 - kbeg) * 4);
+    }
+  };
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < C::A_F4; ++i) {
-      const int r = rA0 + i * A_RSTEP;
-      if (A_FULL || r < C::RA) {
-        const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
-        const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
-        const int rlim = (LA == LAY_K) ? p.M : kend;
-        const int clim = (LA == LAY_K) ? kend : p.M;
-        ra[i] = *reinterpret_cast<const f32x4*>(Ag + (int64_t)min(grow, rlim - 1) * p.lda + min(gcol, last_chunk(clim)));
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < C::B_F4; ++i) {
-      const int r = rB0 + i * B_RSTEP;
-      if (B_FULL || r < C::RB) {
-        const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
-        const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
-        const int rlim = (LB == LAY_K) ? Nv : kend;
-        const int clim = (LB == LAY_K) ? kend : Nv;
-        rb[i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(grow, rlim - 1) * p.ldb + min(gcol, last_chunk(clim)));
-      }
-    }
-    if constexpr (PRO_ON_A) {
-      const int gc = min(k0 + cA, last_chunk(kend));
-      pv0 = *reinterpret_cast<const f32x4*>(pro0 + gc);
-      pv1 = *reinterpret_cast<const f32x4*>(pro1 + gc);
-    }
+    for (int u = 0; u < NSTAGE; ++u) load_unit(u, k0);
+    load_pro(k0);
   };
   auto transform = [&](f32x4 v) {
     f32x4 o;
@@ -293,101 +363,138 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     }
     return o;
   };
-  // prologue + zero fill + write to LDS of the tile that was loaded for reduction offset k0
-  auto store_tiles = [&](int k0, int buf) {
+  // prologue + zero fill + write to LDS of one unit of the tile that was loaded for reduction offset k0
+  auto store_unit = [&](int u, int k0, int buf) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     float* As = lds + buf * C::LDS_TILES;
     float* Bs = As + C::RA * SA;
-#pragma unroll
-    for (int i = 0; i < C::A_F4; ++i) {
-      const int r = rA0 + i * A_RSTEP;
+    const int kleft = kend - k0;   // valid reduction indices from k0 on (may be <= 0 for a tile past the end)
+    if (u < C::A_F4) {
+      const int i = u, r = rA0 + i * A_RSTEP;
       if (A_FULL || r < C::RA) {
-        const int grow = (LA == LAY_K) ? m0 + r : k0 + r;
-        const int gcol = (LA == LAY_K) ? k0 + cA : m0 + cA;
-        const bool ok = grow < ((LA == LAY_K) ? p.M : kend) && gcol < ((LA == LAY_K) ? kend : p.M);
+        const bool ok = inA[i] && (((LA == LAY_K) ? cA : r) < kleft);
         f32x4 v = ra[i];
         if constexpr (PRO_ON_A) v = transform(v);
         *reinterpret_cast<f32x4*>(As + r * SA + cA) = ok ? v : zero;
       }
-    }
-#pragma unroll
-    for (int i = 0; i < C::B_F4; ++i) {
-      const int r = rB0 + i * B_RSTEP;
+    } else {
+      const int i = u - C::A_F4, r = rB0 + i * B_RSTEP;
       if (B_FULL || r < C::RB) {
-        const int grow = (LB == LAY_K) ? n0 + r : k0 + r;
-        const int gcol = (LB == LAY_K) ? k0 + cB : n0 + cB;
-        const bool ok = grow < ((LB == LAY_K) ? Nv : kend) && gcol < ((LB == LAY_K) ? kend : Nv);
+        const bool ok = inB[i] && (((LB == LAY_K) ? cB : r) < kleft);
         f32x4 v = rb[i];
         if constexpr (PRO_ON_B) v = transform(v);
         *reinterpret_cast<f32x4*>(Bs + r * SB + cB) = ok ? v : zero;
       }
     }
   };
+  auto store_tiles = [&](int k0, int buf) {
+#pragma unroll
+    for (int u = 0; u < NSTAGE; ++u) store_unit(u, k0, buf);
+  };
 
-  auto mfma_tile = [&](int buf) {
+  // fragments of k sub-step kk (8 reduction indices: lane half h holds 4*h .. 4*h+3) of the tile in LDS buffer `buf`
+  auto frag_load = [&](int buf, int kk, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
     const float* As = lds + buf * C::LDS_TILES;
     const float* Bs = As + C::RA * SA;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) {
+      int row = wm * TM * 32 + i * 32 + l32;
+      if (LA == LAY_K) {
+        af[i] = *reinterpret_cast<const f32x4*>(As + row * SA + kk * 8 + 4 * h);
+      } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int row = wm * TM * 32 + i * 32 + l32;
-        if (LA == LAY_K) {
-          af[i] = *reinterpret_cast<const f32x4*>(As + row * SA + kk * 8 + 4 * h);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) af[i][j] = As[(kk * 8 + 4 * h + j) * SA + row];
-        }
+        for (int j = 0; j < 4; ++j) af[i][j] = As[(kk * 8 + 4 * h + j) * SA + row];
       }
+    }
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        int col = wn * TN * 32 + i * 32 + l32;
-        if (LB == LAY_K) {
-          bf[i] = *reinterpret_cast<const f32x4*>(Bs + col * SB + kk * 8 + 4 * h);
-        } else {
+    for (int i = 0; i < TN; ++i) {
+      int col = wn * TN * 32 + i * 32 + l32;
+      if (LB == LAY_K) {
+        bf[i] = *reinterpret_cast<const f32x4*>(Bs + col * SB + kk * 8 + 4 * h);
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(kk * 8 + 4 * h + j) * SB + col];
-        }
+        for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(kk * 8 + 4 * h + j) * SB + col];
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int im = 0; im < TM; ++im)
-#pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
     }
   };
+  auto mfma_j = [&](int j, const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+    for (int im = 0; im < TM; ++im)
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+  };
+  auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mfma_j(j, af, bf);
+  };
 
+  constexpr int NG = BK / 8;   // k sub-steps per tile
   if constexpr (NBUF == 1) {
+    f32x4 af[TM], bf[TN];
     if (kbeg < kend) load_tiles(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       __syncthreads();                 // previous tile fully consumed
       store_tiles(k0, 0);
       __syncthreads();
       if (k0 + BK < kend) load_tiles(k0 + BK);   // raw prefetch into registers; consumed after the MFMAs below
-      mfma_tile(0);
+#pragma unroll
+      for (int kk = 0; kk < NG; ++kk) {
+        frag_load(0, kk, af, bf);
+        mfma_group(af, bf);
+      }
     }
   } else {
-    // double-buffered: tile s+1 goes from registers into the other LDS buffer and tile s+2 from memory into registers
-    // while the MFMAs of tile s run; one barrier per reduction step
+    // Double-buffered and software-pipelined, one barrier per tile.  While the MFMAs of sub-step g of tile s issue,
+    // the fragments of sub-step g+1 are read from LDS; during sub-step 0, tile s+1 goes from registers into the other
+    // LDS buffer and tile s+2 from memory into registers.  The barrier sits before the last sub-step, whose MFMAs
+    // (operands already in registers) cover the fragment reads of the next tile.  Staging is unconditional: loads
+    // are clamped into the matrix and a tile past the end of the reduction is zeros that nobody reads.
+    static_assert(NG % 2 == 0, "fragment registers alternate by sub-step parity");
     const int nsteps = (kend - kbeg + BK - 1) / BK;
+    f32x4 af[2][TM], bf[2][TN];
     if (nsteps > 0) {
       load_tiles(kbeg);
       store_tiles(kbeg, 0);
+      load_tiles(kbeg + BK);
+      __syncthreads();
+      frag_load(0, 0, af[0], bf[0]);
     }
-    if (nsteps > 1) load_tiles(kbeg + BK);
-    __syncthreads();
+    MRL_KT(0);
     for (int st = 0; st < nsteps; ++st) {
       const int k0 = kbeg + st * BK, cur = st & 1;
-      if (st + 1 < nsteps) store_tiles(k0 + BK, cur ^ 1);
-      if (st + 2 < nsteps) load_tiles(k0 + 2 * BK);
-      mfma_tile(cur);
-      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+          frag_load(cur, g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+        } else {
+          MRL_KT(1 + st * 2);
+          __syncthreads();
+          MRL_KT(2 + st * 2);
+          frag_load(cur ^ 1, 0, af[0], bf[0]);
+        }
+        if (g == 0) {
+          // the staging units are spread over the four MFMA batches of this sub-step; the scheduler may interleave
+          // inside a batch but not move work from one batch to another
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mfma_j(j, af[0], bf[0]);
+#pragma unroll
+            for (int u = j * NSTAGE / 4; u < (j + 1) * NSTAGE / 4; ++u) {
+              store_unit(u, k0 + BK, cur ^ 1);
+              load_unit(u, k0 + 2 * BK);
+            }
+            if (j == 3) load_pro(k0 + 2 * BK);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          mfma_group(af[g & 1], bf[g & 1]);
+        }
+      }
     }
   }
   __syncthreads();   // LDS is reused as reduction scratch below
+  MRL_KT(1001);
 
   // element (im, in, r) of this lane: row = rbase(im) + (r&3) + 8*(r>>2), col = cbase(in)
   auto rowof = [&](int im, int r) { return wm * TM * 32 + im * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; };
@@ -821,6 +928,8 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
       }
     }
   }
+  MRL_KT(1002);
+  MRL_KB(1);
 }
 
 }  // namespace mrl

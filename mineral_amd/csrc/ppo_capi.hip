@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <utility>
@@ -109,6 +110,9 @@ static inline int bwd_bm(int n) { return n == 512 ? BWD512_BM : 128; }
 // wide layers take the streaming LayerNorm backward: rows per block of that kernel
 static inline bool ln_bwd_streamed(int n) { return n >= 256; }
 static inline int ln_bwd_rows(int64_t rows) { int64_t r = cdiv(rows, 512); return (int)(r < 4 ? 4 : cdiv(r, 4) * 4); }
+
+constexpr int MRL_LDS_PER_CU = 160 * 1024;   // gfx950
+constexpr int MRL_WGRAD_RESIDENT = 2;        // blocks per CU the split-K plan is sized for
 
 struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 
@@ -247,8 +251,27 @@ extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flo
   return MRL_OK;
 }
 
+// `resident` > 0 caps the blocks of this launch that share a CU: unused dynamic LDS is requested so that exactly
+// that many fit (a grid of resident x CUs blocks then spreads evenly instead of stacking up on part of the CUs).
+#ifdef MRL_KTRACE
+// instrumented diagnostic build only: copy the cycle stamps of the traced block to host memory
+extern "C" int mrl_debug_ktrace(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * 4 * KTRACE_SLOTS) == hipSuccess ? 0 : -3;
+}
+extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_kblock), sizeof(unsigned long long) * 2 * KTRACE_BLOCKS) == hipSuccess ? 0 : -3;
+}
+#endif
+
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2>
-static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
+static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident = 0) {
+  using Cfg = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
+  constexpr int static_lds = 4 * ((NBUF * Cfg::LDS_TILES > Cfg::LDS_EPI) ? NBUF * Cfg::LDS_TILES : Cfg::LDS_EPI);
+  unsigned dyn_lds = 0;
+  if (resident > 0) {
+    const int per_block = (MRL_LDS_PER_CU / resident) & ~1023;
+    if (per_block > static_lds) dyn_lds = (unsigned)(per_block - static_lds);
+  }
   static int cls = [] {
     char nm[96];
     snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
@@ -261,7 +284,20 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), 0, s, p);
+#ifdef MRL_KTRACE
+  GemmP pt = p;
+  {
+    static const char* want = getenv("MRL_KTRACE");
+    static const char* want_m = getenv("MRL_KTRACE_M");
+    char nm[96];
+    snprintf(nm, sizeof(nm), "<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
+    static const char* want_z = getenv("MRL_KTRACE_Z");
+    pt.ktrace = (want && strcmp(want, nm) == 0 && (!want_m || atoi(want_m) == p.M)) ? 1 + (want_z ? atoi(want_z) : 0) : 0;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), dyn_lds, s, pt);
+#else
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), dyn_lds, s, p);
+#endif
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -289,11 +325,11 @@ template <int PRO>
 static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
   dim3 grid(slab_grid(w.nsplit, w.tiles_m * w.tiles_n), 1, towers);
   if (w.bm == 32)
-    launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
+    launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else if (w.bn == 64)
-    launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
+    launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else
-    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s);
+    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
 }
 
 static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers, hipStream_t s) {
