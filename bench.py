@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--num-envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--minibatch', type=int, default=32768, help='minibatch rows per GPU')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo = rehearsal of the multi-rank path through host memory (ranks may share a GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -90,12 +92,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     multi = world > 1
+    if args.backend == 'gloo':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = f'cuda:{local_rank}'
     if multi:
         import torch.distributed as dist
+        from mineral_amd import parallel
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        else:
+            dist.init_process_group('gloo')
+        coll = parallel.collectives(dist)
 
     from mineral_amd import _hip
     from mineral_amd.agents import PPO
@@ -115,8 +124,9 @@ def main():
         agent.train_epoch()
 
     def fence():
+        torch.cuda.synchronize()
         if multi:
-            dist.barrier()
+            coll.barrier()
         torch.cuda.synchronize()
 
     L = _hip.lib()
@@ -136,8 +146,13 @@ def main():
     dt = time.perf_counter() - t0
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # every rank must hold the same parameters after the same number of optimizer steps
+        sums = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        flat = agent.model.flat.double()
+        coll.all_gather(sums, torch.stack([flat.sum(), (flat * flat).sum()]))
+        in_sync = all(bool(torch.equal(sums[0], x)) for x in sums[1:])
 
     env_steps = args.num_envs * T_HORIZON * world * args.steps
     out = {
@@ -150,6 +165,8 @@ def main():
                    'num_envs_total': args.num_envs * world, 'ms_per_update': 1e3 * dt / args.steps,
                    'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
     }
+    if multi:
+        out['ranks_in_sync'] = in_sync
     if rank == 0:
         if timing:
             import ctypes as C
@@ -162,11 +179,11 @@ def main():
                 out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                    'traffic': None, 'kernel': name.value.decode(), 'launches': int(n.value),
                                    'avg_launch_us': 1e3 * ms.value / n.value}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not multi:   # the CPU leg is timed at N=1 only
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if multi:
-        dist.barrier()
+        coll.barrier()
         dist.destroy_process_group()
 
 

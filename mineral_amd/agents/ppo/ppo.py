@@ -147,9 +147,9 @@ class PPO(Agent):
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError('multi_gpu=True needs an initialised torch.distributed process group (backend nccl)')
-            self._dist = dist
+            self._dist = parallel.collectives(dist)
             flat = self.model.flat
-            dist.broadcast(flat, src=0)   # DDP's initial parameter broadcast
+            self._dist.broadcast(flat, src=0)   # DDP's initial parameter broadcast
 
     # ---------------------------------------------------------------------------------------------------------------
     def _stream(self):

@@ -88,6 +88,7 @@ struct GemmP {
   HeadsP h;
 #ifdef MRL_KTRACE
   int ktrace;                  // instrumented diagnostic build only: 1 + z = block 8 of tower z records cycle stamps
+  int ablate;                  // bit 0: no staging, bit 1: no fragment reads, bit 2: no barrier, bit 3: no MFMA (results are garbage)
 #endif
 };
 
@@ -97,6 +98,7 @@ constexpr int KTRACE_SLOTS = 1024;
 __device__ unsigned long long g_ktrace[4][KTRACE_SLOTS];
 constexpr int KTRACE_BLOCKS = 8192;
 __device__ unsigned long long g_kblock[KTRACE_BLOCKS][2];   // 100 MHz clock at entry / exit of every block
+#define MRL_ABLATE(bit) ((p.ablate >> (bit)) & 1)
 #define MRL_KB(which)                                                                                    \
   do {                                                                                                   \
     const unsigned kb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
@@ -109,6 +111,7 @@ __device__ unsigned long long g_kblock[KTRACE_BLOCKS][2];   // 100 MHz clock at 
   } while (0)
 #else
 #define MRL_KT(slot) do { } while (0)
+#define MRL_ABLATE(bit) false
 #define MRL_KB(which) do { } while (0)
 #endif
 
@@ -463,32 +466,35 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     MRL_KT(0);
     for (int st = 0; st < nsteps; ++st) {
       const int k0 = kbeg + st * BK, cur = st & 1;
+      MRL_KT(400 + st);
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) {
-          frag_load(cur, g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+          if (!MRL_ABLATE(1)) frag_load(cur, g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
         } else {
           MRL_KT(1 + st * 2);
-          __syncthreads();
+          if (!MRL_ABLATE(2)) __syncthreads();
           MRL_KT(2 + st * 2);
-          frag_load(cur ^ 1, 0, af[0], bf[0]);
+          if (!MRL_ABLATE(1)) frag_load(cur ^ 1, 0, af[0], bf[0]);
         }
         if (g == 0) {
           // the staging units are spread over the four MFMA batches of this sub-step; the scheduler may interleave
           // inside a batch but not move work from one batch to another
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            mfma_j(j, af[0], bf[0]);
+            if (!MRL_ABLATE(3)) mfma_j(j, af[0], bf[0]);
+            if (!MRL_ABLATE(0)) {
 #pragma unroll
-            for (int u = j * NSTAGE / 4; u < (j + 1) * NSTAGE / 4; ++u) {
-              store_unit(u, k0 + BK, cur ^ 1);
-              load_unit(u, k0 + 2 * BK);
+              for (int u = j * NSTAGE / 4; u < (j + 1) * NSTAGE / 4; ++u) {
+                store_unit(u, k0 + BK, cur ^ 1);
+                load_unit(u, k0 + 2 * BK);
+              }
+              if (j == 3) load_pro(k0 + 2 * BK);
             }
-            if (j == 3) load_pro(k0 + 2 * BK);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-          mfma_group(af[g & 1], bf[g & 1]);
+          if (!MRL_ABLATE(3)) mfma_group(af[g & 1], bf[g & 1]);
         }
       }
     }

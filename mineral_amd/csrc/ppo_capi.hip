@@ -112,7 +112,7 @@ static inline bool ln_bwd_streamed(int n) { return n >= 256; }
 static inline int ln_bwd_rows(int64_t rows) { int64_t r = cdiv(rows, 512); return (int)(r < 4 ? 4 : cdiv(r, 4) * 4); }
 
 constexpr int MRL_LDS_PER_CU = 160 * 1024;   // gfx950
-constexpr int MRL_WGRAD_RESIDENT = 2;        // blocks per CU the split-K plan is sized for
+constexpr int MRL_WGRAD_RESIDENT = 0;        // blocks per CU the split-K plan is sized for
 
 struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 
@@ -292,7 +292,9 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
     char nm[96];
     snprintf(nm, sizeof(nm), "<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
     static const char* want_z = getenv("MRL_KTRACE_Z");
+    static const char* abl = getenv("MRL_KTRACE_ABLATE");
     pt.ktrace = (want && strcmp(want, nm) == 0 && (!want_m || atoi(want_m) == p.M)) ? 1 + (want_z ? atoi(want_z) : 0) : 0;
+    pt.ablate = (pt.ktrace && abl) ? atoi(abl) : 0;
   }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), dyn_lds, s, pt);
 #else
@@ -329,7 +331,7 @@ static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hip
   else if (w.bn == 64)
     launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else
-    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
+    launch_gemm<128, 128, 32, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
 }
 
 static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers, hipStream_t s) {
@@ -1130,7 +1132,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
       p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
       p.n_groups = p.m_tiles; p.group_mode = 0;
-      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
+      launch_gemm<128, 128, 32, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
       LnBwdArgs a;
       for (int tw = 0; tw < 2; ++tw) {
         a.dz[tw] = ws + W.dz[tw][l]; a.xhat[tw] = ws + W.xhat[tw][l]; a.rstd[tw] = ws + W.rstd[tw][l];

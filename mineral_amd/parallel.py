@@ -4,6 +4,46 @@ the GPUs, gloo in the CPU tests).  Envs are sharded over ranks; these helpers ar
 import torch
 
 
+class HostStaged:
+    """torch.distributed look-alike for process groups that only take CPU tensors (gloo): device tensors go through
+    host memory with synchronous copies, in and out.  Used to rehearse the multi-rank path where RCCL cannot run
+    (several ranks sharing one GPU); the product path hands torch.distributed itself (backend nccl) to the agent."""
+
+    def __init__(self, dist):
+        self._d = dist
+
+    def is_initialized(self):
+        return self._d.is_initialized()
+
+    def all_reduce(self, t, op=None):
+        h = t.detach().cpu()
+        if op is None:
+            self._d.all_reduce(h)
+        else:
+            self._d.all_reduce(h, op=op)
+        t.copy_(h)
+        return t
+
+    def all_gather(self, outs, t):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        self._d.all_gather(hs, t.detach().cpu())
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+
+    def broadcast(self, t, src=0):
+        h = t.detach().cpu()
+        self._d.broadcast(h, src=src)
+        t.copy_(h)
+
+    def barrier(self):
+        self._d.barrier()
+
+
+def collectives(dist):
+    """The object the agent calls its collectives on: torch.distributed for nccl, the host-staged wrapper for gloo."""
+    return HostStaged(dist) if dist.get_backend() == 'gloo' else dist
+
+
 def combine_moments(mean, var, count, dist, world_size):
     """Merge per-rank batch moments of equally sized shards into the moments of their union.
 

@@ -3,6 +3,7 @@ golden vectors of the reference.  Integer / index results must be bit-exact; fp3
 written at each comparison (the GEMMs sum in a different order than torch's CPU kernels).
 """
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -447,3 +448,23 @@ def test_full_size_properties(hip):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]), 'gradients are bit-reproducible'
     assert torch.isfinite(metrics).all()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_through_host_staged_gloo():
+    """The multi-rank agent path (parameter broadcast, sharded GAE statistics, merged observation moments, gradient
+    all-reduce, KL all-reduce) run as two processes on this GPU with gloo through host memory: both ranks must end
+    with bit-identical parameters.  RCCL itself needs one GPU per rank and is exercised by the scaling benchmark."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--backend', 'gloo',
+           '--num-envs', '1024', '--minibatch', '4096', '--no-kernel-timing']
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['ranks_in_sync'] is True
+    assert out['value'] > 0

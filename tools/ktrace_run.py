@@ -93,6 +93,9 @@ def main():
               f'barrier wait median {int(np.median(wait))} (max {int(wait.max())})')
         if w == 0:
             print('   work per step:', ' '.join(str(int(x)) for x in work))
+            top = tw[400:400 + nsteps]
+            print('   first sub-step (top -> barrier):', ' '.join(str(int(x)) for x in (arrive - top)))
+            print('   last sub-step (barrier -> next top):', ' '.join(str(int(x)) for x in (top[1:] - leave[:-1])))
     skew = t[:, 1:1 + 2 * nsteps:2]
     print('arrival skew between the four waves of the block (max - min), median over steps:', int(np.median(skew.max(0) - skew.min(0))))
 
