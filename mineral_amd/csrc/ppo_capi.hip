@@ -331,7 +331,7 @@ static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hip
   else if (w.bn == 64)
     launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else
-    launch_gemm<128, 128, 32, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
+    launch_gemm<128, 128, 16, 2, 2, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
 }
 
 static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers, hipStream_t s) {
@@ -1132,7 +1132,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
       p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
       p.n_groups = p.m_tiles; p.group_mode = 0;
-      launch_gemm<128, 128, 32, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
+      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
       LnBwdArgs a;
       for (int tw = 0; tw < 2; ++tw) {
         a.dz[tw] = ws + W.dz[tw][l]; a.xhat[tw] = ws + W.xhat[tw][l]; a.rstd[tw] = ws + W.rstd[tw][l];
