@@ -18,6 +18,10 @@ resources: $(SRC) $(HDR)
 ktrace: $(SRC) $(HDR)
 	mkdir -p tools/bin && $(HIPCC) $(HIPFLAGS) -DMRL_KTRACE $(SRC) -o tools/bin/libmineral_ppo_ktrace.so
 
+# the same with the main-loop ablation switches of tools/ktrace_ablate.sh compiled in
+ktrace-ablate: $(SRC) $(HDR)
+	mkdir -p tools/bin && $(HIPCC) $(HIPFLAGS) -DMRL_KTRACE -DMRL_KTRACE_ABLATE $(SRC) -o tools/bin/libmineral_ppo_ktrace.so
+
 clean:
 	rm -f $(LIB)
-.PHONY: all resources ktrace clean
+.PHONY: all resources ktrace ktrace-ablate clean

@@ -74,6 +74,18 @@ def cpu_baseline(num_envs=16384, minibatch=32768, threads=None):
                       f'torch-CPU oracle, {dt:.1f} s'}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` at this workload, from the committed rocprofv3 counter passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs by tools/pmc_traffic.sh and cannot be read from inside this process);
+    None when no measurement of that kernel is on file."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)['kernels'][kernel]['hbm_bytes']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -176,8 +188,9 @@ def main():
             if n.value > 0:
                 achieved = flops.value / (ms.value * 1e-3) / 1e12
                 peak = 157.3
+                kname = name.value.decode()
                 out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                                   'traffic': None, 'kernel': name.value.decode(), 'launches': int(n.value),
+                                   'traffic': measured_traffic(kname), 'kernel': kname, 'launches': int(n.value),
                                    'avg_launch_us': 1e3 * ms.value / n.value}
         if not args.no_cpu_baseline and not multi:   # the CPU leg is timed at N=1 only
             out['cpu_baseline'] = cpu_baseline()

@@ -98,7 +98,11 @@ constexpr int KTRACE_SLOTS = 1024;
 __device__ unsigned long long g_ktrace[4][KTRACE_SLOTS];
 constexpr int KTRACE_BLOCKS = 8192;
 __device__ unsigned long long g_kblock[KTRACE_BLOCKS][2];   // 100 MHz clock at entry / exit of every block
+#ifdef MRL_KTRACE_ABLATE   // switches inside the main loop change its code; a build of its own keeps the stamps honest
 #define MRL_ABLATE(bit) ((p.ablate >> (bit)) & 1)
+#else
+#define MRL_ABLATE(bit) false
+#endif
 #define MRL_KB(which)                                                                                    \
   do {                                                                                                   \
     const unsigned kb_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                 \
@@ -558,7 +562,9 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
       const float tot = halving_sum32<16>(sv, l32);
       if (owner) partA[wn * BM + own_row + im * 32] = tot;
     }
+    MRL_KT(1003);
     __syncthreads();
+    MRL_KT(1004);
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
       float qv[16];
@@ -584,12 +590,21 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
       const float tot = halving_sum32<16>(qv, l32);
       if (owner) partB[wn * BM + own_row + im * 32] = tot;
     }
+    MRL_KT(1005);
     __syncthreads();
-    const rsrc_t out_rs = tile_rsrc(p.out[tw] + (int64_t)m0 * BN, BM * BN * 4);
-    const int lane_boff = (((wm * TM * 32 + 4 * h) * BN) + wn * TN * 32 + l32) * 4;
+    MRL_KT(1006);
+    // xhat leaves through a per-wave LDS transpose: the accumulator layout (one column, 16 rows per lane) would need
+    // one 4-byte store per element; 32 x XW sub-blocks are rewritten row-major in LDS and stored 16 bytes per lane
+    // (rows >= M of the last block are written too: the activation workspace is padded to whole row tiles)
+    constexpr int XI = TN >= 2 ? 2 : 1, XW = 32 * XI, XS = XW + 8;   // row stride = 8 mod 16 floats: conflict-free writes
+    static_assert(2 * BM * WGN + 4 * 32 * XS <= LDS_ALL, "LDS too small for the store transpose");
+    static_assert(TN % XI == 0, "column blocks are transposed in pairs");
+    float* xs = lds + 2 * BM * WGN + wave * 32 * XS;
+    float* outp = p.out[tw] + (int64_t)m0 * BN;
     float* rs = p.rstd[tw];
 #pragma unroll
-    for (int im = 0; im < TM; ++im)
+    for (int im = 0; im < TM; ++im) {
+      float rstd_r[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
@@ -598,14 +613,28 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
         for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partB + w * BM + base);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          // rows >= M of the last block are written too: the activation workspace is padded to whole row tiles
           const float rstd = 1.0f / sqrtf(t[rr] * invn + p.ln_eps);
-#pragma unroll
-          for (int in = 0; in < TN; ++in)
-            buf_store(ea[im][in][g * 4 + rr] * rstd, out_rs, lane_boff, ((im * 32 + 8 * g + rr) * BN + in * 32) * 4);
+          rstd_r[g * 4 + rr] = rstd;
           if (wn == 0 && l32 == 0) rs[m0 + base + rr] = rstd;
         }
       }
+#pragma unroll
+      for (int ip = 0; ip < TN; ip += XI) {
+#pragma unroll
+        for (int i2 = 0; i2 < XI; ++i2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            xs[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + i2 * 32 + l32] = ea[im][ip + i2][r] * rstd_r[r];
+        // same wave wrote and reads: LDS executes a wave's operations in order
+        const int row0 = wm * TM * 32 + im * 32, col0 = wn * TN * 32 + ip * 32;
+#pragma unroll
+        for (int q = 0; q < 32 * XW / 4 / 64; ++q) {
+          const int idx = q * 64 + lane, row = idx / (XW / 4), ch = idx % (XW / 4);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xs + row * XS + ch * 4);
+          *reinterpret_cast<f32x4*>(outp + (int64_t)(row0 + row) * BN + col0 + ch * 4) = v;
+        }
+      }
+    }
   } else if constexpr (EPI == EPI_LNBWD) {
     // work on scalars from here on: element-wise updates of the 16-wide accumulator vectors cost whole-vector copies
     float ea[TM][TN][16];

@@ -78,6 +78,10 @@ def main():
         print('   slowest block ids:', ids[order[-16:]].tolist())
         print('   fastest block ids:', ids[order[:16]].tolist())
         print(f'{len(b)} blocks (us, percentiles 0/10/50/90/100): start {q(st)} | end {q(en)} | duration {q(en - st)}')
+    if t[0, 1003]:
+        x = t[:, 1001:1007]
+        for w in range(4):
+            print(f'wave {w} LayerNorm epilogue: sums {int(x[w, 2] - x[w, 0])}, barrier {int(x[w, 3] - x[w, 2])}, deviations {int(x[w, 4] - x[w, 3])}, barrier {int(x[w, 5] - x[w, 4])}, rstd + stores {int(t[w, 1002] - x[w, 5])}')
     print(f'kernel {os.environ.get("MRL_KTRACE")} M={os.environ.get("MRL_KTRACE_M")}: {nsteps} reduction steps traced')
     if nsteps < 2:
         return
