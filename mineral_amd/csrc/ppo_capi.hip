@@ -13,10 +13,6 @@
 
 using namespace mrl;
 
-#ifndef BWD512_BM
-#define BWD512_BM 32
-#endif
-
 static thread_local char g_err[512] = "";
 
 #define MRL_FAIL(code, ...)                      \
@@ -106,7 +102,6 @@ extern "C" int mrl_param_offsets(const mrl_net* net, int64_t* offs, int32_t* n) 
 }
 
 static inline int fwd_bm(int n) { return n == 512 ? 64 : 128; }   // rows per block of the full-row (LayerNorm) tiles
-static inline int bwd_bm(int n) { return n == 512 ? BWD512_BM : 128; }
 // wide layers take the streaming LayerNorm backward: rows per block of that kernel
 static inline bool ln_bwd_streamed(int n) { return n >= 256; }
 static inline int ln_bwd_rows(int64_t rows) { int64_t r = cdiv(rows, 512); return (int)(r < 4 ? 4 : cdiv(r, 4) * 4); }
@@ -157,7 +152,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
       w->rstd[tw][l] = o; o = align64(o + rows_pad);
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
-      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, bwd_bm(u));
+      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, 128);
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
@@ -1143,7 +1138,11 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
       if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
     } else {
-      MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_R, 16, EPI_LNBWD, PRO_NONE, p, 2, s);
+      // narrow layers (<= 128 wide): the whole row fits one block's accumulators, LayerNorm backward fused
+      const dim3 grid((unsigned)cdiv(p.M, 128), 1, 2);
+      if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
     }
   }
 
