@@ -468,3 +468,25 @@ def test_two_ranks_share_one_gpu_through_host_staged_gloo():
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['ranks_in_sync'] is True
     assert out['value'] > 0
+
+
+@pytest.mark.gpu
+def test_launcher_cli_trains_and_writes_the_reference_artifacts(tmp_path):
+    """`python -m mineral.scripts.run task=Synthetic ...` (the drop-in launch line) trains for a few epochs on the HIP path
+    and leaves the on-disk artefacts of mineral/scripts/run.py:34-41 and ppo.py:416-426."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logdir = str(tmp_path / 'run')
+    cmd = [sys.executable, '-m', 'mineral.scripts.run', 'task=Synthetic', 'num_envs=256', 'agent.ppo.minibatch_size=2048',
+           'agent.ppo.max_agent_steps=24576', 'agent.print_every=1', f'logdir={logdir}', 'seed=3']
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert 'Traceback' not in res.stderr and 'Exception:' not in res.stdout, (res.stdout[-1500:], res.stderr[-1500:])
+    for rel in ('run_metadata.yaml', 'resolved_config.yaml', 'ckpt/final.pth'):
+        assert os.path.exists(os.path.join(logdir, rel)), rel
+    ckpt = torch.load(os.path.join(logdir, 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
+    assert {'epoch', 'mini_epoch', 'agent_steps', 'model', 'optim', 'obs_rms', 'value_rms'} <= set(ckpt)
+    assert ckpt['agent_steps'] == 24576 and ckpt['epoch'] == 2
+    assert 'actor_mlp.mlp.0.weight' in ckpt['model'] and ckpt['obs_rms']['obs.running_count'].dtype == torch.float64
