@@ -1,8 +1,8 @@
 # Builds the gfx950 shared library (C ABI) in-tree.  `make` here, on CPU: hipcc cross-compiles.
 HIPCC ?= /opt/rocm/bin/hipcc
 HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-value
-SRC = mineral_amd/csrc/ppo_capi.hip
-HDR = mineral_amd/csrc/gemm.hip.h include/mineral_ppo.h
+SRC = mineral_amd/csrc/ppo_capi.hip mineral_amd/csrc/replay.hip
+HDR = mineral_amd/csrc/gemm.hip.h include/mineral_ppo.h include/mineral_replay.h
 LIB = mineral_amd/libmineral_ppo.so
 
 all: $(LIB)

@@ -1,4 +1,4 @@
-"""ctypes binding of `libmineral_ppo.so` (the C ABI declared in include/mineral_ppo.h).
+"""ctypes binding of `libmineral_ppo.so` (the C ABI declared in include/mineral_ppo.h and include/mineral_replay.h).
 
 The library is the product: there is no Python/torch fallback.  If it has not been built (`make` at the repo
 root) importing a function from here raises immediately.
@@ -42,6 +42,14 @@ class PpoHp(C.Structure):
                 ('bounds_type', C.c_int32), ('clip_value_loss', C.c_int32)]
 
 
+class Transitions(C.Structure):
+    """mrl_transitions: structure-of-arrays view of a set of transitions (include/mineral_replay.h)."""
+    _fields_ = [('obs', C.c_void_p), ('action', C.c_void_p), ('reward', C.c_void_p), ('next_obs', C.c_void_p), ('done', C.c_void_p),
+                ('obs_dim', C.c_int32), ('act_dim', C.c_int32)]
+
+
+NSTEP_MAX = 7
+
 _P = C.c_void_p
 _SIGNATURES = {
     'mrl_last_error': (C.c_char_p, []),
@@ -62,6 +70,10 @@ _SIGNATURES = {
                                C.c_float, _P, _P, _P, C.c_int64, _P]),
     'mrl_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                 C.c_int64, C.c_float, C.c_float, _P, _P, _P]),
+    'mrl_nstep_emit': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int32, C.POINTER(Transitions), C.c_int64, C.c_int32, _P,
+                                 C.POINTER(Transitions), _P]),
+    'mrl_replay_write': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int64, C.POINTER(Transitions), C.c_int64, _P]),
+    'mrl_replay_gather': (C.c_int, [C.POINTER(Transitions), C.c_int64, _P, C.c_int64, C.POINTER(Transitions), _P]),
     'mrl_profile_enable': (C.c_int, [C.c_int]),
     'mrl_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
 }

@@ -28,6 +28,11 @@ static thread_local char g_err[512] = "";
   } while (0)
 
 extern "C" const char* mrl_last_error(void) { return g_err; }
+
+// for the other translation units of the library (replay.hip)
+namespace mrl {
+void set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+}  // namespace mrl
 extern "C" int mrl_version(void) { return 1; }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -102,3 +102,41 @@ class GoldenEnv:
         done = self.counters >= self.episode_length
         self.counters = torch.where(done, torch.zeros_like(self.counters), self.counters)
         return obs.to(self.device), rew.to(self.device), done.to(self.device), {'time_outs': done.to(self.device)}
+
+
+# ---- replay-buffer scenarios (shared by make_golden_replay.py and the tests) ------------------------------------
+REPLAY_NSTEP_CASES = {
+    # name: (num_envs, obs_dim, act_dim, nstep, gamma, horizon of each consecutive add_to_buffer call, done probability)
+    'n3': (6, 8, 4, 3, 0.99, (4, 1, 5, 2), 0.25),
+    'n5': (5, 4, 2, 5, 0.97, (6, 3, 7), 0.3),
+    'n1': (4, 4, 2, 1, 0.99, (3, 2), 0.25),
+    'n3_nodone': (3, 4, 2, 3, 0.99, (6,), 0.0),
+}
+REPLAY_RING_CASES = {
+    # name: (capacity, obs_dim, act_dim, rows of each consecutive add)
+    'wrap': (40, 8, 4, (18, 18, 18, 7, 40)),
+    'exact': (36, 4, 2, (18, 18, 5)),
+    'short': (64, 4, 2, (10, 3)),
+}
+
+
+def replay_call_inputs(case, call, seed):
+    """Trajectory of one explore call: obs / next_obs (N,T,O), actions (N,T,A), rewards (N,T,1), dones (N,T,1) float."""
+    N, O, A, nstep, gamma, horizons, pdone = REPLAY_NSTEP_CASES[case]
+    T = horizons[call]
+    s = seed * 100 + call * 10
+    obs = gaussianish((N, T, O), s + 1)
+    nxt = gaussianish((N, T, O), s + 2)
+    act = lcg_t((N, T, A), s + 3, 2.0)
+    rew = gaussianish((N, T, 1), s + 4)
+    done = (lcg_t((N, T, 1), s + 5, 1.0) + 0.5 < pdone).float()
+    return obs, act, rew, nxt, done
+
+
+def replay_rows(case, add, seed):
+    """Flat transitions of one ReplayBuffer.add_to_buffer call: obs, actions, rewards, next_obs, dones."""
+    cap, O, A, rows = REPLAY_RING_CASES[case]
+    n = rows[add]
+    s = seed * 100 + add * 10
+    return (gaussianish((n, O), s + 1), lcg_t((n, A), s + 2, 2.0), gaussianish((n, 1), s + 3), gaussianish((n, O), s + 4),
+            (lcg_t((n, 1), s + 5, 1.0) > 0.2).float())

@@ -20,9 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    text = open(os.path.join(ROOT, 'include', 'mineral_ppo.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(mrl_[a-z0-9_]+)\s*\(', text)))
+    names = set()
+    for header in ('mineral_ppo.h', 'mineral_replay.h'):
+        text = open(os.path.join(ROOT, 'include', header)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        names |= set(re.findall(r'\b(mrl_[a-z0-9_]+)\s*\(', text))
+    return sorted(names)
 
 
 def test_abi_exports_every_declared_symbol():
@@ -31,7 +34,7 @@ def test_abi_exports_every_declared_symbol():
     names = header_functions()
     assert len(names) >= 15
     for n in names:
-        assert hasattr(lib, n), f'{n} is declared in include/mineral_ppo.h but not exported'
+        assert hasattr(lib, n), f'{n} is declared in include/*.h but not exported'
     assert sorted(_hip.EXPORTS) == names, 'the ctypes binding and the header must list the same entry points'
     assert lib.mrl_version() >= 1
 
