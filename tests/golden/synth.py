@@ -140,3 +140,36 @@ def replay_rows(case, add, seed):
     s = seed * 100 + add * 10
     return (gaussianish((n, O), s + 1), lcg_t((n, A), s + 2, 2.0), gaussianish((n, 1), s + 3), gaussianish((n, O), s + 4),
             (lcg_t((n, 1), s + 5, 1.0) > 0.2).float())
+
+
+class SacGoldenEnv(GoldenEnv):
+    """GoldenEnv whose even-numbered envs end by time-out and odd-numbered ones by a real termination, so that
+    `handle_timeout` (mineral/agents/agent.py:158-167) leaves some done flags set."""
+
+    def step(self, actions):
+        obs, rew, done, info = super().step(actions)
+        even = (torch.arange(self.num_envs) % 2 == 0).to(done.device)
+        return obs, rew, done, {'time_outs': done & even}
+
+
+SAC_CASES = {
+    # name: (num_envs, obs_dim, act_dim, actor units, critic units, hparams, epochs)
+    'small': (8, 8, 4, [64, 32], [64, 32], dict(warm_up=4, horizon_len=4, batch_size=16, memory_size=72, nstep=3, mini_epochs=2), 3),
+    'mid': (16, 12, 4, [128, 64, 32], [128, 64, 32], dict(warm_up=6, horizon_len=5, batch_size=64, memory_size=4096, nstep=3, mini_epochs=3), 2),
+}
+
+
+def sac_uniform(shape, counter):
+    """Stand-in for torch.rand: U[0,1)."""
+    return lcg_t(tuple(shape), 7000 + counter, 1.0) + 0.5
+
+
+def sac_noise(shape, counter):
+    """Stand-in for Normal.rsample's standard-normal draw."""
+    return gaussianish(tuple(shape), 8000 + counter)
+
+
+def sac_indices(high, n, counter):
+    """Stand-in for torch.randint(high, (n,))."""
+    u = torch.from_numpy(lcg((n,), 9000 + counter, 1.0, np.float64) + 0.5)
+    return (u * high).long().clamp_(0, high - 1)
