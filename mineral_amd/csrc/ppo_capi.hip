@@ -44,9 +44,10 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct ParamLayout {
   int64_t W[2][MRL_MAX_LAYERS], b[2][MRL_MAX_LAYERS], g[2][MRL_MAX_LAYERS], be[2][MRL_MAX_LAYERS];
-  int64_t Wh[2], bh[2];   // heads: actor [2A][U] / [2A], critic [1][U] / [1]
+  int64_t Wh[2], bh[2];   // heads: [head_rows][U] / [head_rows] per tower
   int64_t total;
   int in_dim[MRL_MAX_LAYERS];
+  int n_towers, head_rows[2];
 };
 
 static int check_net(const mrl_net* net) {
@@ -62,12 +63,15 @@ static int check_net(const mrl_net* net) {
   return MRL_OK;
 }
 
-static void param_layout(const mrl_net* net, ParamLayout* L) {
+// Flat layout of `n_towers` MLP towers ([W, b, ln_gamma, ln_beta] per layer) followed by one head per tower
+// ([head_rows][U] weights, [head_rows] bias); every tensor starts at a multiple of 4 floats.
+static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int n_towers, const int* head_rows, ParamLayout* L) {
   int64_t o = 0;
-  for (int tw = 0; tw < 2; ++tw) {
-    int in = net->obs_dim;
-    for (int l = 0; l < net->n_layers; ++l) {
-      int u = net->units[l];
+  memset(L, 0, sizeof(*L));
+  for (int tw = 0; tw < n_towers; ++tw) {
+    int in = in_dim0;
+    for (int l = 0; l < n_layers; ++l) {
+      int u = units[l];
       L->in_dim[l] = in;
       L->W[tw][l] = o; o = align4(o + (int64_t)u * in);
       L->b[tw][l] = o; o = align4(o + u);
@@ -76,12 +80,20 @@ static void param_layout(const mrl_net* net, ParamLayout* L) {
       in = u;
     }
   }
-  int U = net->units[net->n_layers - 1], A = net->act_dim;
-  L->Wh[0] = o; o = align4(o + (int64_t)2 * A * U);
-  L->bh[0] = o; o = align4(o + 2 * A);
-  L->Wh[1] = o; o = align4(o + U);
-  L->bh[1] = o; o = align4(o + 1);
+  const int U = units[n_layers - 1];
+  for (int tw = 0; tw < n_towers; ++tw) {
+    L->head_rows[tw] = head_rows[tw];
+    L->Wh[tw] = o; o = align4(o + (int64_t)head_rows[tw] * U);
+    L->bh[tw] = o; o = align4(o + head_rows[tw]);
+  }
+  L->n_towers = n_towers;
   L->total = o;
+}
+
+// ActorCritic: actor tower with the [mu; sigma] head, critic tower with the value head
+static void param_layout(const mrl_net* net, ParamLayout* L) {
+  const int hr[2] = {2 * net->act_dim, 1};
+  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L);
 }
 
 extern "C" int64_t mrl_param_count(const mrl_net* net) {
@@ -1045,6 +1057,148 @@ extern "C" int mrl_rms_normalize(const mrl_rms* rms, const float* x, float* y, i
   return MRL_OK;
 }
 
+// Backward of `towers` towers (tower indices tw0 .. tw0+towers-1 of the workspace / layout) from the head seeds
+// ws[W.seeds[tw]] ([rows][32], zero padded): dgrad chain with the LayerNorm/SiLU backward of every layer, then (wgrad)
+// the partial weight-gradient slabs of every layer and head, and (input_grad) the gradient with respect to the first
+// layer's input, one [rows][in_dim] matrix per tower.
+static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
+                              const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
+                              float* const* input_grad, hipStream_t s) {
+  const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  // ---- dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) --------------------------
+  for (int l = last; l >= 0; --l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const int u = net->units[l];
+    for (int k = 0; k < towers; ++k) {
+      const int tw = tw0 + k;
+      if (l == last) {
+        p.A[k] = ws + W.seeds[tw];
+        p.B[k] = params + L.Wh[tw];
+        p.Kt[k] = L.head_rows[tw];
+      } else {
+        p.A[k] = ws + W.dz[tw][l + 1];
+        p.B[k] = params + L.W[tw][l + 1];
+        p.Kt[k] = net->units[l + 1];
+      }
+      p.Nt[k] = u;
+      p.out[k] = ws + W.dz[tw][l];
+      p.xhat[k] = ws + W.xhat[tw][l];
+      p.rstd[k] = ws + W.rstd[tw][l];
+      p.gamma[k] = params + L.g[tw][l];
+      p.beta[k] = params + L.be[tw][l];
+      p.colpart[k] = ws + W.colpart[tw][l];
+    }
+    const int kdim = (l == last) ? 32 : net->units[l + 1];
+    p.lda = kdim; p.ldb = u; p.ldo = u;
+    p.M = (int)mb; p.N = u; p.K = kdim;
+    if (ln_bwd_streamed(u)) {
+      // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
+      p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
+      p.n_groups = p.m_tiles; p.group_mode = 0;
+      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+      LnBwdArgs a;
+      memset(&a, 0, sizeof(a));
+      for (int k = 0; k < towers; ++k) {
+        const int tw = tw0 + k;
+        a.dz[k] = ws + W.dz[tw][l]; a.xhat[k] = ws + W.xhat[tw][l]; a.rstd[k] = ws + W.rstd[tw][l];
+        a.gamma[k] = params + L.g[tw][l]; a.beta[k] = params + L.be[tw][l]; a.colpart[k] = ws + W.colpart[tw][l];
+      }
+      a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
+      dim3 grid(W.rowblocks[l], towers);
+      if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
+    } else {
+      // narrow layers (<= 128 wide): the whole row fits one block's accumulators, LayerNorm backward fused
+      const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
+      if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+    }
+  }
+
+  // ---- gradient with respect to the input of the first layer: dX = dZ0 * W0 ----------------------------------------
+  if (input_grad) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const int u0 = net->units[0], in0 = L.in_dim[0];
+    for (int k = 0; k < towers; ++k) {
+      const int tw = tw0 + k;
+      p.A[k] = ws + W.dz[tw][0];
+      p.B[k] = params + L.W[tw][0];
+      p.Kt[k] = u0; p.Nt[k] = in0;
+      p.out[k] = input_grad[k];
+    }
+    p.lda = u0; p.ldb = in0; p.ldo = in0;
+    p.M = (int)mb; p.N = in0; p.K = u0;
+    p.ksplit = u0; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = (int)cdiv(in0, 128);
+    p.n_groups = p.m_tiles; p.group_mode = 0;
+    launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+  }
+  if (!wgrad) return;
+
+  // ---- wgrad partial slabs -----------------------------------------------------------------------------------------
+  for (int l = last + 1; l >= 0; --l) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const bool head = (l == last + 1);
+    const int gm = head ? 32 : net->units[l];
+    const int gn = head ? U : L.in_dim[l];
+    const WgradPlan& wp = head ? W.wph : W.wp[l];
+    for (int k = 0; k < towers; ++k) {
+      const int tw = tw0 + k;
+      p.A[k] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
+      p.B[k] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
+      p.pro0[k] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
+      p.pro1[k] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
+      p.out[k] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
+      p.Nt[k] = gn; p.Kt[k] = (int)mb;
+    }
+    p.lda = gm; p.ldb = gn; p.ldo = gn;
+    p.M = gm; p.N = gn; p.K = (int)mb;
+    p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
+    p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
+    p.n_groups = wp.nsplit; p.group_mode = 1;
+    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU, towers, s);
+  }
+}
+
+// Fixed-order reduction of the partial slabs, column partials and head-bias partials of towers tw0 .. tw0+towers-1
+// into the flat gradient vector (layout L).  hblocks = 128-row blocks that produced head-bias partials.
+static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, float* grads, int tw0, int towers, int hblocks,
+                               hipStream_t s) {
+  const int nl = net->n_layers, U = net->units[nl - 1];
+  // alignment gaps between tensors of the flat gradient are never produced by a kernel: start from zeros
+  // (a fill kernel, not hipMemsetAsync, so that the sequence can be captured in a graph)
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)cdiv(L.total, 1024)), dim3(256), 0, s, grads, L.total);
+  ReduceTable tab;
+  tab.n = 0;
+  auto add = [&](const float* src, int64_t off, int64_t count, int64_t stride, int nslabs) {
+    ReduceDesc& d = tab.d[tab.n++];
+    d.src = src; d.dst = grads + off; d.count = count; d.stride = stride; d.nslabs = nslabs;
+  };
+  int64_t maxcount = 0;
+  for (int k = 0; k < towers; ++k) {
+    const int tw = tw0 + k;
+    for (int l = 0; l < nl; ++l) {
+      const int u = net->units[l];
+      add(ws + W.slab[tw][l], L.W[tw][l], (int64_t)u * L.in_dim[l], (int64_t)u * L.in_dim[l], W.wp[l].nsplit);
+      const float* cp = ws + W.colpart[tw][l];
+      add(cp + 2 * u, L.b[tw][l], u, 3 * u, W.rowblocks[l]);
+      add(cp, L.g[tw][l], u, 3 * u, W.rowblocks[l]);
+      add(cp + u, L.be[tw][l], u, 3 * u, W.rowblocks[l]);
+      if ((int64_t)u * L.in_dim[l] > maxcount) maxcount = (int64_t)u * L.in_dim[l];
+    }
+    const int hn = L.head_rows[tw];
+    add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
+    // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
+    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(hn), 64, hblocks);
+  }
+  int gx = (int)cdiv(maxcount, 64);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
+}
+
 extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
                             int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
                             float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
@@ -1102,110 +1256,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
                      hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
 
-  // ---- backward: dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) -----------------
-  for (int l = last; l >= 0; --l) {
-    GemmP p;
-    memset(&p, 0, sizeof(p));
-    const int u = net->units[l];
-    for (int tw = 0; tw < 2; ++tw) {
-      if (l == last) {
-        p.A[tw] = ws + W.seeds[tw];
-        p.B[tw] = params + L.Wh[tw];
-        p.Kt[tw] = (tw == 0) ? 2 * A : 1;
-      } else {
-        p.A[tw] = ws + W.dz[tw][l + 1];
-        p.B[tw] = params + L.W[tw][l + 1];
-        p.Kt[tw] = net->units[l + 1];
-      }
-      p.Nt[tw] = u;
-      p.out[tw] = ws + W.dz[tw][l];
-      p.xhat[tw] = ws + W.xhat[tw][l];
-      p.rstd[tw] = ws + W.rstd[tw][l];
-      p.gamma[tw] = params + L.g[tw][l];
-      p.beta[tw] = params + L.be[tw][l];
-      p.colpart[tw] = ws + W.colpart[tw][l];
-    }
-    const int kdim = (l == last) ? 32 : net->units[l + 1];
-    p.lda = kdim; p.ldb = u; p.ldo = u;
-    p.M = (int)mb; p.N = u; p.K = kdim;
-    if (ln_bwd_streamed(u)) {
-      // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
-      p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
-      p.n_groups = p.m_tiles; p.group_mode = 0;
-      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, 2), s);
-      LnBwdArgs a;
-      for (int tw = 0; tw < 2; ++tw) {
-        a.dz[tw] = ws + W.dz[tw][l]; a.xhat[tw] = ws + W.xhat[tw][l]; a.rstd[tw] = ws + W.rstd[tw][l];
-        a.gamma[tw] = params + L.g[tw][l]; a.beta[tw] = params + L.be[tw][l]; a.colpart[tw] = ws + W.colpart[tw][l];
-      }
-      a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
-      dim3 grid(W.rowblocks[l], 2);
-      if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
-    } else {
-      // narrow layers (<= 128 wide): the whole row fits one block's accumulators, LayerNorm backward fused
-      const dim3 grid((unsigned)cdiv(p.M, 128), 1, 2);
-      if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
-      else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
-      else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
-    }
-  }
-
-  // ---- backward: wgrad partial slabs -----------------------------------------------------------------------------
-  for (int l = last + 1; l >= 0; --l) {
-    GemmP p;
-    memset(&p, 0, sizeof(p));
-    const bool head = (l == last + 1);
-    const int gm = head ? 32 : net->units[l];
-    const int gn = head ? U : L.in_dim[l];
-    const WgradPlan& wp = head ? W.wph : W.wp[l];
-    for (int tw = 0; tw < 2; ++tw) {
-      p.A[tw] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
-      p.B[tw] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
-      p.pro0[tw] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
-      p.pro1[tw] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
-      p.out[tw] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
-      p.Nt[tw] = gn; p.Kt[tw] = (int)mb;
-    }
-    p.lda = gm; p.ldb = gn; p.ldo = gn;
-    p.M = gm; p.N = gn; p.K = (int)mb;
-    p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
-    p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
-    p.n_groups = wp.nsplit; p.group_mode = 1;
-    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU, 2, s);
-  }
-
-  // alignment gaps between tensors of the flat gradient are never produced by a kernel: start from zeros
-  // (a fill kernel, not hipMemsetAsync, so that the sequence can be captured in a graph)
-  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)cdiv(L.total, 1024)), dim3(256), 0, s, grads, L.total);
-  // ---- reduce partial slabs into the flat gradient -----------------------------------------------------------------
-  ReduceTable tab;
-  tab.n = 0;
-  auto add = [&](const float* src, int64_t off, int64_t count, int64_t stride, int nslabs) {
-    ReduceDesc& d = tab.d[tab.n++];
-    d.src = src; d.dst = grads + off; d.count = count; d.stride = stride; d.nslabs = nslabs;
-  };
-  int64_t maxcount = 0;
-  for (int tw = 0; tw < 2; ++tw) {
-    for (int l = 0; l < nl; ++l) {
-      const int u = net->units[l];
-      add(ws + W.slab[tw][l], L.W[tw][l], (int64_t)u * L.in_dim[l], (int64_t)u * L.in_dim[l], W.wp[l].nsplit);
-      const float* cp = ws + W.colpart[tw][l];
-      add(cp + 2 * u, L.b[tw][l], u, 3 * u, W.rowblocks[l]);
-      add(cp, L.g[tw][l], u, 3 * u, W.rowblocks[l]);
-      add(cp + u, L.be[tw][l], u, 3 * u, W.rowblocks[l]);
-      if ((int64_t)u * L.in_dim[l] > maxcount) maxcount = (int64_t)u * L.in_dim[l];
-    }
-    const int hn = (tw == 0) ? 2 * A : 1;
-    add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
-    // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
-    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(hn), 64, hblocks);
-  }
-  {
-    int gx = (int)cdiv(maxcount, 64);
-    if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
-  }
+  launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s);
+  launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
   return MRL_OK;
 }
