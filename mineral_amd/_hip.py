@@ -49,6 +49,22 @@ class Transitions(C.Structure):
 
 
 NSTEP_MAX = 7
+SAC_NMETRIC = 8
+
+
+class SacNet(C.Structure):
+    """mrl_sac_net (include/mineral_sac.h)."""
+    _fields_ = [('obs_dim', C.c_int32), ('act_dim', C.c_int32), ('actor_layers', C.c_int32), ('actor_units', C.c_int32 * MAX_LAYERS),
+                ('critic_layers', C.c_int32), ('critic_units', C.c_int32 * MAX_LAYERS), ('minlogstd', C.c_float), ('maxlogstd', C.c_float),
+                ('ln_eps', C.c_float)]
+
+
+def make_sac_net(obs_dim, act_dim, actor_units, critic_units, minlogstd=-5.0, maxlogstd=2.0, ln_eps=1e-5):
+    if len(actor_units) > MAX_LAYERS or len(critic_units) > MAX_LAYERS:
+        raise NotImplementedError(f'at most {MAX_LAYERS} layers per tower')
+    au = (C.c_int32 * MAX_LAYERS)(*actor_units)
+    cu = (C.c_int32 * MAX_LAYERS)(*critic_units)
+    return SacNet(obs_dim, act_dim, len(actor_units), au, len(critic_units), cu, minlogstd, maxlogstd, ln_eps)
 
 _P = C.c_void_p
 _SIGNATURES = {
@@ -74,6 +90,15 @@ _SIGNATURES = {
                                  C.POINTER(Transitions), _P]),
     'mrl_replay_write': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int64, C.POINTER(Transitions), C.c_int64, _P]),
     'mrl_replay_gather': (C.c_int, [C.POINTER(Transitions), C.c_int64, _P, C.c_int64, C.POINTER(Transitions), _P]),
+    'mrl_sac_param_count': (C.c_int64, [C.POINTER(SacNet), C.c_int32]),
+    'mrl_sac_param_offsets': (C.c_int, [C.POINTER(SacNet), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'mrl_sac_workspace_bytes': (C.c_int64, [C.POINTER(SacNet), C.c_int64]),
+    'mrl_sac_actor_sample': (C.c_int, [C.POINTER(SacNet), _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, C.c_int64, _P]),
+    'mrl_sac_critic_grad': (C.c_int, [C.POINTER(SacNet), _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.POINTER(Transitions), C.c_int64, _P,
+                                      C.c_float, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    'mrl_sac_actor_grad': (C.c_int, [C.POINTER(SacNet), _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.c_int64, _P, C.c_float, _P, _P, _P, _P,
+                                     C.c_int64, _P]),
+    'mrl_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     'mrl_profile_enable': (C.c_int, [C.c_int]),
     'mrl_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
 }

@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { LAY_K = 0, LAY_R = 1 };           // LAY_K: reduction index contiguous; LAY_R: reduction index = row
 enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2 };
 enum { EPI_LNFWD = 0, EPI_LNBWD = 1, EPI_SLAB = 2, EPI_HEADS_TRAIN = 3, EPI_HEADS_ACT = 4 };
-enum { DIST_NORMAL = 0, DIST_DREAMERV3 = 1 };
+enum { DIST_NORMAL = 0, DIST_DREAMERV3 = 1, DIST_SQUASHED = 2 };   // DIST_SQUASHED: rollout-style sampling only (SAC)
 
 #define MRL_LOG_SQRT_2PI 0.91893853320467274178f
 #define MRL_NMETRIC 12
@@ -806,13 +806,34 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           mu = tanhf(o);
           sg = sigmoid_f(ls + 2.0f);
           sigma = (hp.maxstd - hp.minstd) * sg + hp.minstd;
+        } else if (hp.dist_type == DIST_SQUASHED) {  // mineral/nets/dist.py:39-43; minstd / maxstd carry the logstd clamp
+          mu = o;
+          sigma = expf(fminf(fmaxf(ls, hp.minstd), hp.maxstd));
         } else {                                   // mineral/nets/dist.py:32-34
           mu = o;
           sigma = expf(ls);
         }
         if (!jv) { mu = 0.f; sigma = 1.f; }
         const float logsig = logf(sigma);
-        if constexpr (EPI == EPI_HEADS_ACT) {
+        if (EPI == EPI_HEADS_ACT && hp.dist_type == DIST_SQUASHED) {
+          // rsample + log_prob of the tanh-squashed normal (mineral/nets/distributions.py:10-52, sac.py:118-136):
+          // u = mu + sigma*eps, a = tanh(u), log p = sum_j [ log N(u_j) - 2*(log 2 - u_j - softplus(-2 u_j)) ]
+          const float eps = jv ? hp.noise[(int64_t)rowc * A + l32] : 0.f;
+          const float u = mu + sigma * eps;
+          const float a = tanhf(u);
+          const float d = u - mu;
+          const float x2 = -2.0f * u;
+          const float sp = x2 > 20.0f ? x2 : log1pf(expf(x2));
+          float lp = jv ? (-(d * d) / (2.0f * sigma * sigma) - logsig - MRL_LOG_SQRT_2PI) - 2.0f * (0.69314718055994530942f - u - sp) : 0.f;
+          lp = group_sum16(lp);
+          if (rv && jv) {
+            const int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + l32;
+            hp.act_out[o_idx] = a;
+            hp.mu[o_idx] = ls;          // the raw log-std: the backward needs to know where the clamp was active
+            hp.sigma[o_idx] = sigma;
+          }
+          if (rv && l32 == 0) hp.neglogp_out[row] = lp;   // the log-probability itself
+        } else if constexpr (EPI == EPI_HEADS_ACT) {
           // mineral/agents/ppo/models.py:115-117 with sample = mu + sigma * noise
           float eps = jv ? hp.noise[(int64_t)rowc * A + l32] : 0.f;
           float a = mu + sigma * eps;

@@ -1295,3 +1295,8 @@ extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, 
   MRL_CHECK_LAUNCH("mrl_adam_step");
   return MRL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// SAC update loop (include/mineral_sac.h) on the same helpers
+// ---------------------------------------------------------------------------------------------------------------
+#include "sac_capi.hip.inc"
