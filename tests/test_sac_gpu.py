@@ -170,3 +170,96 @@ def test_sac_gradients_vs_oracle(O, A, au, cu, B):
     _hip.check(L.mrl_polyak(_hip.ptr(ft2), _hip.ptr(fc), ft2.numel(), 0.05, None), 'polyak')
     expect = ft.cpu().clone().mul_(1.0 - 0.05).add_(fc.cpu() * 0.05)
     assert torch.equal(ft2.cpu(), expect)
+
+
+def _sac_cfg(case, logdir):
+    from mineral_amd.config import Config
+    N, O, A, au, cu, hp, epochs = synth.SAC_CASES[case]
+    mlp = lambda u: dict(units=u, norm_type='LayerNorm', act_type='SiLU')
+    sac = dict(multi_gpu=False, num_actors=N, reward_shaper=dict(fn='scale', scale=0.5), max_agent_steps=N * (hp['warm_up'] + epochs * hp['horizon_len']),
+               tau=0.05, gamma=0.99, no_tgt_actor=True, handle_timeout=True, update_actor_interval=1, update_targets_interval=1, init_alpha=0.7,
+               alpha=None, alpha_optim_kwargs=dict(lr=5e-3), backup_entropy=True, optim_type='AdamW', actor_optim_kwargs=dict(lr=5e-4),
+               critic_optim_kwargs=dict(lr=5e-4), max_grad_norm=0.5)
+    sac.update(hp)
+    return Config.wrap(dict(
+        rl_device=DEV, sim_device=DEV, multi_gpu=False, env_render=False, run='train', seed=42,
+        task=dict(name='Golden', env=dict(numEnvs=N), env_autoresets=True),
+        agent=dict(algo='SAC', print_every=-1, ckpt_every=-1, tracker_len=100, metrics_kwargs={},
+                   network=dict(normalize_input=True, encoder=None, actor='Actor',
+                                actor_kwargs=dict(mlp_kwargs=mlp(au), weight_init='orthogonal', tanh_policy=False, fixed_sigma=False,
+                                                  dist_kwargs=dict(dist_type='squashed_normal', minlogstd=-5.0, maxlogstd=2.0)),
+                                critic='EnsembleQ', critic_kwargs=dict(n_critics=2, mlp_kwargs=mlp(cu), weight_init='orthogonal')),
+                   sac=sac)))
+
+
+@pytest.mark.parametrize('case', sorted(synth.SAC_CASES))
+def test_sac_agent_training_run_vs_reference(case, tmp_path):
+    """The product agent (`SAC.train()`: warm-up, explore, n-step + ring buffer, update_net) against the run recorded from the
+    reference agent with the same injected draws.  Replay contents are compared bit for bit where they do not depend on the
+    policy (warm-up); parameters after every epoch within the tolerance of fp32 GEMMs in a different summation order."""
+    from mineral_amd.agents import SAC
+    G = np.load(os.path.join(ROOT, 'tests', 'golden', f'g12_sac_{case}.npz'))
+    N, O, A, au, cu, hp, epochs = synth.SAC_CASES[case]
+    cfg = _sac_cfg(case, str(tmp_path))
+    env = synth.SacGoldenEnv(N, O, A, episode_length=5, device=DEV)
+    agent = SAC(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    agent._checkpoint_save = lambda *a, **k: None
+    ocfg = S.SACConfig(O, A, au, cu)
+    agent.actor.load_state_dict(synth.make_params(S.actor_shapes(ocfg), 21), strict=True)
+    agent.critic.load_state_dict(synth.make_params(S.critic_shapes(ocfg), 22), strict=True)
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    counters = {'rand': 0, 'noise': 0, 'idx': 0}
+
+    def draw(kind, fn, *a):
+        counters[kind] += 1
+        return fn(*a, counters[kind] - 1)
+
+    agent.rand_fn = lambda shape: draw('rand', synth.sac_uniform, shape)
+    agent.noise_fn = lambda shape: draw('noise', synth.sac_noise, shape)
+    agent.index_fn = lambda high, n: draw('idx', synth.sac_indices, high, n)
+    seen = []
+    orig = agent.update_net
+
+    def spy(memory):
+        res = orig(memory)
+        torch.cuda.synchronize()
+        e = agent.epoch
+        seen.append(e)
+        assert [counters[k] for k in ('rand', 'noise', 'idx')] == [int(x) for x in G[f'e{e}_counters']]
+        assert (memory.next_p, memory.cur_capacity, int(memory.if_full)) == tuple(int(x) for x in G[f'e{e}_memory_state'])
+        k = memory.cur_capacity
+        assert np.array_equal(memory.buf_done[:k].cpu().numpy(), G[f'e{e}_memory_done'])
+        assert np.allclose(memory.buf_reward[:k].cpu().numpy(), G[f'e{e}_memory_reward'], rtol=0, atol=1e-5)
+        if e == 0:
+            # the first rows come from the warm-up (uniform actions, no policy involved): exact copies / fp32 n-step sums
+            w = N * (hp['warm_up'] - hp['nstep'] + 1)
+            assert np.array_equal(memory.buf_obs['obs'][:w].cpu().numpy(), G['e0_memory_obs'][:w])
+            assert np.array_equal(memory.buf_action[:w].cpu().numpy(), G['e0_memory_action'][:w])
+            assert np.array_equal(memory.buf_reward[:w].cpu().numpy(), G['e0_memory_reward'][:w])
+            assert np.allclose(memory.buf_action[:k].cpu().numpy(), G['e0_memory_action'], atol=5e-5)
+        rms = agent.obs_rms['obs']
+        assert np.allclose(rms.running_mean.cpu().numpy(), G[f'e{e}_obs_rms.running_mean'], rtol=1e-5, atol=1e-6)
+        assert np.allclose(rms.running_var.cpu().numpy(), G[f'e{e}_obs_rms.running_var'], rtol=1e-5, atol=1e-6)
+        for name, v in agent.actor.state_dict().items():
+            ref = G[f'e{e}_actor.{name}']
+            assert np.allclose(v.cpu().numpy(), ref, rtol=2e-3, atol=3e-5), (e, name, float(np.abs(v.cpu().numpy() - ref).max()))
+        for name, v in agent.critic.state_dict().items():
+            ref = G[f'e{e}_critic.{name}']
+            assert np.allclose(v.cpu().numpy(), ref, rtol=2e-3, atol=3e-5), (e, name, float(np.abs(v.cpu().numpy() - ref).max()))
+        assert abs(float(agent.log_alpha.cpu()) - float(G[f'e{e}_log_alpha'])) < 2e-5
+        for key in ('loss/critic', 'loss/actor', 'loss/alpha', 'entropy', 'grad_norm/critic', 'grad_norm/actor'):
+            got = res[key].float().cpu().numpy()
+            ref = G[f'e{e}_{key.replace("/", "_")}']
+            assert np.allclose(got, ref, rtol=2e-3, atol=2e-4), (e, key, got, ref)
+        if e == epochs - 1:
+            for name, v in agent.critic_target.state_dict().items():
+                assert np.allclose(v.cpu().numpy(), G[f'e{e}_critic_target.{name}'], rtol=2e-3, atol=3e-5), name
+        return res
+
+    agent.update_net = spy
+    agent.train()
+    assert seen == list(range(epochs))
+    # checkpoint keys of sac.py:418-432
+    ckpt = torch.load(os.path.join(str(tmp_path), 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
+    assert {'epoch', 'mini_epoch', 'agent_steps', 'obs_rms', 'encoder', 'actor', 'critic', 'encoder_target', 'actor_target', 'critic_target', 'log_alpha'} <= set(ckpt)
+    assert 'critics.1.mlp.0.weight' in ckpt['critic'] and 'sigma.bias' in ckpt['actor']
