@@ -321,9 +321,22 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
   }
 }
 
-// full-row tiles, selected by the output width
+// full-row tiles, selected by the output width; batches of at most MRL_SMALL_M rows take 32-row tiles so that a
+// 2048-row minibatch still spreads over 64 blocks per tower instead of 16
+constexpr int MRL_SMALL_M = 8192;
 #define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, PRO, p, towers, s)                                                     \
   do {                                                                                                                    \
+    if (p.M <= MRL_SMALL_M) {                                                                                             \
+      const dim3 g_((unsigned)cdiv(p.M, 32), 1, towers);                                                                  \
+      switch (N) {                                                                                                        \
+        case 512: launch_gemm<32, 512, 16, 1, 4, LA, LB, EPI, PRO, 1>(p, g_, s); break;                                   \
+        case 256: launch_gemm<32, 256, 16, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                      \
+        case 128: launch_gemm<32, 128, BKBIG, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                   \
+        case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+        default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
+      }                                                                                                                   \
+      break;                                                                                                              \
+    }                                                                                                                     \
     switch (N) {                                                                                                          \
       case 512: launch_gemm<64, 512, 16, 1, 4, LA, LB, EPI, PRO, 1>(p, dim3((unsigned)cdiv(p.M, 64), 1, towers), s); break;        \
       case 256: launch_gemm<128, 256, 16, 2, 2, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \

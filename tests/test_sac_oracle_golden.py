@@ -22,14 +22,20 @@ def test_sac_training_run_matches_reference(case):
     def check(e, st):
         seen.append(e)
         assert [st['counters'][k] for k in ('rand', 'noise', 'idx')] == [int(x) for x in G[f'e{e}_counters']]
-        # replay contents are copies and fp32 sums in the reference's order: bit-exact
+        # replay contents: copies and fp32 n-step sums in the reference's order.  The rows of the warm-up (uniform actions) do
+        # not depend on the policy and must match bit for bit; later rows carry policy actions, whose last bits depend on
+        # how the CPU GEMMs were threaded when the vectors were recorded
         mem = st['mem']
         assert (mem.next_p, mem.cur_capacity, int(mem.if_full)) == tuple(int(x) for x in G[f'e{e}_memory_state'])
         k = mem.cur_capacity
-        assert np.array_equal(mem.reward[:k], G[f'e{e}_memory_reward']) and np.array_equal(mem.done[:k], G[f'e{e}_memory_done'])
+        assert np.array_equal(mem.done[:k], G[f'e{e}_memory_done'])
+        assert np.allclose(mem.reward[:k], G[f'e{e}_memory_reward'], rtol=0, atol=1e-6)
         if e == 0:
-            assert np.array_equal(mem.obs[:k], G['e0_memory_obs']) and np.array_equal(mem.action[:k], G['e0_memory_action'])
-            assert np.array_equal(mem.next_obs[:k], G['e0_memory_next_obs'])
+            N, hpc = synth.SAC_CASES[case][0], synth.SAC_CASES[case][5]
+            w = N * (hpc['warm_up'] - hpc['nstep'] + 1)
+            for got, key in ((mem.obs, 'obs'), (mem.action, 'action'), (mem.next_obs, 'next_obs'), (mem.reward, 'reward')):
+                assert np.array_equal(got[:w], G[f'e0_memory_{key}'][:w]), key
+                assert np.allclose(got[:k], G[f'e0_memory_{key}'], rtol=0, atol=1e-5), key
         # running statistics, parameters, log_alpha: same torch ops in the same order; tolerance for op fusion only
         for key in ('running_mean', 'running_var', 'running_count'):
             assert torch.allclose(st['obs_rms'][key], torch.from_numpy(G[f'e{e}_obs_rms.{key}']), rtol=1e-6, atol=1e-7), key
