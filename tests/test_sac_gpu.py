@@ -263,3 +263,19 @@ def test_sac_agent_training_run_vs_reference(case, tmp_path):
     ckpt = torch.load(os.path.join(str(tmp_path), 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
     assert {'epoch', 'mini_epoch', 'agent_steps', 'obs_rms', 'encoder', 'actor', 'critic', 'encoder_target', 'actor_target', 'critic_target', 'log_alpha'} <= set(ckpt)
     assert 'critics.1.mlp.0.weight' in ckpt['critic'] and 'sigma.bias' in ckpt['actor']
+
+
+def test_launcher_cli_runs_sac(tmp_path):
+    """`python -m mineral.scripts.run task=Synthetic agent=SyntheticSAC ...` trains SAC on the HIP path and writes final.pth."""
+    import subprocess
+    logdir = str(tmp_path / 'run')
+    cmd = [sys.executable, '-m', 'mineral.scripts.run', 'task=Synthetic', 'agent=SyntheticSAC', 'num_envs=256', 'agent.sac.batch_size=512',
+           'agent.sac.memory_size=50000', 'agent.sac.horizon_len=8', 'agent.sac.warm_up=8', 'agent.sac.mini_epochs=2',
+           'agent.sac.max_agent_steps=8192', 'agent.print_every=1', f'logdir={logdir}', 'seed=5']
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert 'Traceback' not in res.stderr and 'Exception:' not in res.stdout, (res.stdout[-1500:], res.stderr[-1500:])
+    ckpt = torch.load(os.path.join(logdir, 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
+    assert ckpt['agent_steps'] == 8192 and ckpt['epoch'] == 2 and ckpt['mini_epoch'] == 5
+    assert torch.isfinite(ckpt['actor']['mu.weight']).all() and torch.isfinite(ckpt['log_alpha'])
