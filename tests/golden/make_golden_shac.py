@@ -1,0 +1,66 @@
+"""Golden vectors of the SHAC critic side, recorded from the REFERENCE (read-only checkout) on CPU:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_shac.py [/root/reference]
+
+The reference's own `SHAC.compute_target_values`, `CriticDataset` and `SHAC.update_critic` are called on a namespace object
+that carries the attributes those methods read (building the whole agent needs a differentiable simulator).  Inputs come
+from synth.py; the fixture holds outputs only.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.argv = sys.argv[:1] + (sys.argv[1:] or ['/root/reference'])
+
+import make_golden as MG  # noqa: E402,F401  (stubs + reference on sys.path)
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+from mineral.agents.diffrl import models as ref_models  # noqa: E402
+from mineral.agents.diffrl import shac as ref_shac  # noqa: E402
+from mineral.agents.diffrl.utils import CriticDataset, soft_update  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import shac_oracle as S  # noqa: E402  (shape lists only)
+
+out = {}
+for case, (N, T, O, units, n_critics, n_batches, iters, optim_type, lr, max_norm) in synth.SHAC_CASES.items():
+    obs, rew, done, nv = synth.shac_inputs(case)
+    for method in ('td-lambda', 'one-step'):
+        ns = types.SimpleNamespace(critic_method=method, rew_buf=rew, gamma=0.99, lam=0.95, next_values=nv, done_mask=done, num_envs=N, device='cpu',
+                                   horizon_len=T, target_values=torch.zeros(T, N))
+        ref_shac.SHAC.compute_target_values(ns)
+        out[f'{case}_targets_{method}'] = ns.target_values.numpy().copy()
+    targets = torch.from_numpy(out[f'{case}_targets_td-lambda'])
+    critic = ref_models.EnsembleCritic(O, 4, n_critics=n_critics, mlp_kwargs=dict(units=units, norm_type='LayerNorm', act_type='SiLU'),
+                                       weight_init='orthogonal')
+    critic.load_state_dict(synth.make_params(S.critic_shapes(O, units, n_critics), 61), strict=True)
+    OptimCls = getattr(torch.optim, optim_type)
+    optim = OptimCls(critic.parameters(), lr=lr, betas=(0.7, 0.95))
+    cfgd = MG.AttrDict.wrap(dict(truncate_grads=True, max_grad_norm=max_norm))
+    ns = types.SimpleNamespace(critic_iterations=iters, critic_optim=optim, critic=critic, encoder=lambda o: o['obs'], shac_config=cfgd)
+    ns.compute_critic_loss = lambda o, t, **kw: ref_shac.SHAC.compute_critic_loss(ns, o, t, **kw)
+    batch_size = N * T // n_batches
+    dataset = CriticDataset(batch_size, {'obs': obs}, targets, drop_last=False)
+    out[f'{case}_dataset_len'] = np.array([len(dataset), batch_size], dtype=np.int64)
+    o_last, t_last = dataset[len(dataset) - 1]
+    out[f'{case}_last_batch_targets'] = t_last.numpy().copy()
+    res = ref_shac.SHAC.update_critic(ns, dataset)
+    for k, v in res.items():
+        out[f'{case}_{k.replace("/", "_")}'] = torch.stack(v).detach().numpy()
+    for k, v in critic.state_dict().items():
+        out[f'{case}_critic.{k}'] = v.numpy().copy()
+    target = ref_models.EnsembleCritic(O, 4, n_critics=n_critics, mlp_kwargs=dict(units=units, norm_type='LayerNorm', act_type='SiLU'))
+    target.load_state_dict(synth.make_params(S.critic_shapes(O, units, n_critics), 62), strict=True)
+    with torch.no_grad():
+        soft_update(critic, target, 0.2)
+    for k, v in target.state_dict().items():
+        out[f'{case}_target.{k}'] = v.numpy().copy()
+
+path = os.path.join(HERE, 'g13_shac_critic.npz')
+np.savez_compressed(path, **out)
+print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')

@@ -173,3 +173,20 @@ def sac_indices(high, n, counter):
     """Stand-in for torch.randint(high, (n,))."""
     u = torch.from_numpy(lcg((n,), 9000 + counter, 1.0, np.float64) + 0.5)
     return (u * high).long().clamp_(0, high - 1)
+
+
+SHAC_CASES = {
+    # name: (num_envs, horizon, obs_dim, critic units, n_critics, num_critic_batches, critic_iterations, optimizer, lr, max_grad_norm)
+    'shac2': (16, 8, 12, [64, 64], 2, 4, 3, 'AdamW', 5e-4, 0.5),
+    'single': (12, 6, 8, [32, 32], 1, 5, 2, 'Adam', 2e-3, 1.0),     # 72 samples in 5 batches: the last one is short
+}
+
+
+def shac_inputs(case, seed=17):
+    """Rollout buffers of one SHAC epoch: obs (T,N,O), rewards, done mask, next values (T,N)."""
+    N, T, O = SHAC_CASES[case][:3]
+    obs = gaussianish((T, N, O), seed + 1)
+    rew = gaussianish((T, N), seed + 2)
+    done = (lcg_t((T, N), seed + 3, 1.0) + 0.5 < 0.15).float()
+    nv = gaussianish((T, N), seed + 4) * 2.0
+    return obs, rew, done, nv
