@@ -14,7 +14,7 @@ import mineral_amd
 
 __version__ = mineral_amd.__version__
 
-for _name in ('agents', 'agents.ppo', 'agents.sac', 'buffers', 'common', 'envs', 'scripts', 'config', 'parallel'):
+for _name in ('agents', 'agents.ppo', 'agents.sac', 'agents.diffrl', 'buffers', 'common', 'envs', 'scripts', 'config', 'parallel'):
     _mod = importlib.import_module(f'mineral_amd.{_name}')
     sys.modules[f'{__name__}.{_name}'] = _mod
     if '.' not in _name:

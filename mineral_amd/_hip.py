@@ -66,6 +66,18 @@ def make_sac_net(obs_dim, act_dim, actor_units, critic_units, minlogstd=-5.0, ma
     cu = (C.c_int32 * MAX_LAYERS)(*critic_units)
     return SacNet(obs_dim, act_dim, len(actor_units), au, len(critic_units), cu, minlogstd, maxlogstd, ln_eps)
 
+
+class CriticNet(C.Structure):
+    """mrl_critic_net (include/mineral_shac.h)."""
+    _fields_ = [('obs_dim', C.c_int32), ('n_critics', C.c_int32), ('n_layers', C.c_int32), ('units', C.c_int32 * MAX_LAYERS), ('ln_eps', C.c_float)]
+
+
+def make_critic_net(obs_dim, n_critics, units, ln_eps=1e-5):
+    if len(units) > MAX_LAYERS:
+        raise NotImplementedError(f'at most {MAX_LAYERS} layers per tower')
+    return CriticNet(obs_dim, n_critics, len(units), (C.c_int32 * MAX_LAYERS)(*units), ln_eps)
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     'mrl_last_error': (C.c_char_p, []),
@@ -99,6 +111,13 @@ _SIGNATURES = {
     'mrl_sac_actor_grad': (C.c_int, [C.POINTER(SacNet), _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.c_int64, _P, C.c_float, _P, _P, _P, _P,
                                      C.c_int64, _P]),
     'mrl_polyak': (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    'mrl_critic_param_count': (C.c_int64, [C.POINTER(CriticNet)]),
+    'mrl_critic_param_offsets': (C.c_int, [C.POINTER(CriticNet), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'mrl_critic_workspace_bytes': (C.c_int64, [C.POINTER(CriticNet), C.c_int64]),
+    'mrl_tdlambda_targets': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, _P, _P]),
+    'mrl_critic_values': (C.c_int, [C.POINTER(CriticNet), _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int64, _P]),
+    'mrl_critic_mse_grad': (C.c_int, [C.POINTER(CriticNet), _P, _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P]),
+    'mrl_lerp_params': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     'mrl_profile_enable': (C.c_int, [C.c_int]),
     'mrl_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
 }

@@ -1,0 +1,4 @@
+"""Critic side of the reference's SHAC agent on the MI355X (mineral/agents/diffrl/{shac.py,models.py,utils.py}).  The actor
+side back-propagates through a differentiable simulator and stays with the caller."""
+
+from .critic import CriticDataset, CriticLearner, EnsembleCritic, compute_target_values, grad_norm, soft_update

@@ -28,6 +28,17 @@ class _Flat:
     """Named views over a flat parameter vector."""
 
     def __init__(self, net, which, names_shapes, device):
+        count, offs = self._query(net, which)
+        self.param_count = count
+        self.device = torch.device(device)
+        self._layout = list(zip(names_shapes, offs))   # ((names, shapes) per library tensor, offset)
+        self.flat = torch.zeros(count, dtype=torch.float32, device=self.device)
+        self._views = self.views_of(self.flat)
+        self.training = True
+
+    @staticmethod
+    def _query(net, which):
+        """(parameter count, offsets of the library's tensors) of network `which` of an mrl_sac_net."""
         L = _hip.lib()
         count = int(L.mrl_sac_param_count(net, which))
         if count < 0:
@@ -35,12 +46,7 @@ class _Flat:
         offs = (C.c_int64 * (2 * 4 * _hip.MAX_LAYERS + 8))()
         n = C.c_int32(0)
         _hip.check(L.mrl_sac_param_offsets(net, which, offs, C.byref(n)), 'mrl_sac_param_offsets')
-        self.param_count = count
-        self.device = torch.device(device)
-        self._layout = list(zip(names_shapes, list(offs)[: n.value]))   # ((names, shapes) per library tensor, offset)
-        self.flat = torch.zeros(count, dtype=torch.float32, device=self.device)
-        self._views = self.views_of(self.flat)
-        self.training = True
+        return count, list(offs)[: n.value]
 
     def views_of(self, flat):
         v = OrderedDict()

@@ -1313,3 +1313,4 @@ extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, 
 // SAC update loop (include/mineral_sac.h) on the same helpers
 // ---------------------------------------------------------------------------------------------------------------
 #include "sac_capi.hip.inc"
+#include "shac_capi.hip.inc"

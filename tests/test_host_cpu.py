@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_functions():
     names = set()
-    for header in ('mineral_ppo.h', 'mineral_replay.h', 'mineral_sac.h'):
+    for header in ('mineral_ppo.h', 'mineral_replay.h', 'mineral_sac.h', 'mineral_shac.h'):
         text = open(os.path.join(ROOT, 'include', header)).read()
         text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
         names |= set(re.findall(r'\b(mrl_[a-z0-9_]+)\s*\(', text))

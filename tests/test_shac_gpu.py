@@ -1,0 +1,142 @@
+"""Critic side of SHAC through the C ABI: TD(lambda) targets bit-exact against the vectors recorded from the reference, critic
+values / regression gradient against the oracle's autograd (fp32; tolerances written at each comparison), and the host
+mirror's `update_critic` + `soft_update` against the run recorded from the reference's own methods."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+import synth  # noqa: E402
+from oracle import shac_oracle as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+G = np.load(os.path.join(ROOT, 'tests', 'golden', 'g13_shac_critic.npz'))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def targets_hip(rew, done, nv, gamma, lam, method):
+    from mineral_amd.agents.diffrl import compute_target_values
+    return compute_target_values(rew.to(DEV), done.to(DEV), nv.to(DEV), gamma, lam, method).cpu()
+
+
+@pytest.mark.parametrize('case', sorted(synth.SHAC_CASES))
+def test_target_values_bit_exact_vs_reference(case):
+    obs, rew, done, nv = synth.shac_inputs(case)
+    for method in ('td-lambda', 'one-step'):
+        got = targets_hip(rew, done, nv, 0.99, 0.95, method)
+        assert np.array_equal(got.numpy(), G[f'{case}_targets_{method}']), method
+
+
+@pytest.mark.parametrize('N,T,gamma,lam', [(1000, 32, 0.99, 0.95), (4096, 16, 0.97, 0.8), (257, 1, 0.99, 0.0)])
+def test_target_values_bit_exact_vs_oracle(N, T, gamma, lam):
+    rew = synth.gaussianish((T, N), 5)
+    nv = synth.gaussianish((T, N), 6) * 3.0
+    done = (synth.lcg_t((T, N), 7, 1.0) + 0.5 < 0.1).float()
+    for method in ('td-lambda', 'one-step'):
+        want = S.target_values(rew, done, nv, gamma, lam, method)
+        got = targets_hip(rew, done, nv, gamma, lam, method)
+        assert torch.equal(got, want), method
+
+
+def test_target_values_rejects_bad_arguments():
+    from mineral_amd.agents.diffrl import compute_target_values
+    z = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(ValueError):
+        compute_target_values(z, z, z, 0.99, 1.0, 'td-lambda')       # divides by 1 - lambda
+    with pytest.raises(NotImplementedError):
+        compute_target_values(z, z, z, 0.99, 0.95, 'monte-carlo')
+    with pytest.raises(ValueError):
+        compute_target_values(z, z[:2], z, 0.99, 0.95)
+
+
+def make_critic(O, units, n_critics, seed):
+    from mineral_amd.agents.diffrl import EnsembleCritic
+    c = EnsembleCritic(O, None, n_critics=n_critics, mlp_kwargs=dict(units=units, norm_type='LayerNorm', act_type='SiLU'), device=DEV)
+    pc = synth.make_params(S.critic_shapes(O, units, n_critics), seed)
+    c.load_state_dict(pc)
+    return c, pc
+
+
+@pytest.mark.parametrize('rows,O,units,n_critics', [(300, 40, [256, 128], 2), (64, 8, [32, 32], 1), (1000, 60, [512, 256, 128], 2)])
+def test_values_and_gradient_vs_oracle(rows, O, units, n_critics):
+    from mineral_amd.agents.diffrl import CriticLearner
+    c, pc = make_critic(O, units, n_critics, 31)
+    obs = synth.gaussianish((rows, O), 3)
+    tgt = synth.gaussianish((rows,), 4) * 2.0
+    want_v = S.critic_values(pc, obs, units, n_critics)
+    got_v = c(obs.to(DEV), return_type='all').cpu()
+    assert got_v.shape == want_v.shape
+    assert torch.allclose(got_v, want_v, rtol=1e-4, atol=2e-5)
+    vmin, vavg = c(obs.to(DEV), return_type='min_and_avg')
+    assert torch.allclose(vmin.cpu(), want_v.min(0).values, rtol=1e-4, atol=2e-5) and torch.allclose(vavg.cpu(), want_v.mean(0), rtol=1e-4, atol=2e-5)
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    loss = S.critic_loss(leaves, obs, tgt, units, n_critics)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    learner = CriticLearner(c)
+    got_loss = learner.compute_critic_loss({'obs': obs.to(DEV)}, tgt.to(DEV))
+    assert abs(got_loss.item() - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-6
+    got = c.views_of(learner.grads)
+    for k, g in grads.items():
+        # fp32 GEMMs with a different summation order: 3e-4 of the tensor's largest gradient
+        assert (got[k].cpu() - g).abs().max().item() <= 3e-4 * g.abs().max().item() + 1e-7, k
+
+
+def test_gradient_non_finite_entries_become_zero():
+    """update_critic replaces NaN / inf gradient entries by 0 before the optimizer step (shac.py:840-842)."""
+    from mineral_amd.agents.diffrl import CriticLearner
+    c, _ = make_critic(12, [64, 64], 2, 33)
+    obs = synth.gaussianish((128, 12), 3).to(DEV)
+    tgt = synth.gaussianish((128,), 4)
+    tgt[5] = float('inf')
+    learner = CriticLearner(c)
+    learner.compute_critic_loss(obs, tgt.to(DEV))
+    assert torch.isfinite(learner.grads).all()
+
+
+def test_lerp_params_bit_exact():
+    from mineral_amd import _hip
+    cur = synth.gaussianish((100003,), 8)
+    tar = synth.gaussianish((100003,), 9)
+    want = tar.clone()
+    want.mul_(0.2)
+    want.add_((1.0 - 0.2) * cur)
+    t = tar.to(DEV)
+    _hip.check(_hip.lib().mrl_lerp_params(_hip.ptr(t), _hip.ptr(cur.to(DEV)), t.numel(), 0.2, 1.0 - 0.2, stream()), 'mrl_lerp_params')
+    assert torch.equal(t.cpu(), want)
+
+
+@pytest.mark.parametrize('case', sorted(synth.SHAC_CASES))
+def test_update_critic_vs_reference_run(case):
+    from mineral_amd.agents.diffrl import CriticDataset, CriticLearner, soft_update
+    N, T, O, units, n_critics, n_batches, iters, optim_type, lr, max_norm = synth.SHAC_CASES[case]
+    obs, rew, done, nv = synth.shac_inputs(case)
+    targets = targets_hip(rew, done, nv, 0.99, 0.95, 'td-lambda').to(DEV)
+    bs = N * T // n_batches
+    ds = CriticDataset(bs, {'obs': obs.to(DEV)}, targets, drop_last=False)
+    assert [len(ds), bs] == [int(x) for x in G[f'{case}_dataset_len']]
+    assert np.array_equal(ds[len(ds) - 1][1].cpu().numpy(), G[f'{case}_last_batch_targets'])
+    c, _ = make_critic(O, units, n_critics, 61)
+    learner = CriticLearner(c, optim_type, dict(lr=lr, betas=(0.7, 0.95)), critic_iterations=iters, max_grad_norm=max_norm)
+    res = learner.update_critic(ds)
+    for k, v in res.items():
+        # losses and norms of fp32 GEMM chains in another summation order
+        assert np.allclose(torch.stack(v).cpu().numpy(), G[f'{case}_{k.replace("/", "_")}'], rtol=1e-3, atol=1e-5), k
+    for k, v in c.state_dict().items():
+        # parameters after iters * batches Adam steps: Adam's normalisation amplifies gradient rounding on small entries
+        assert torch.allclose(v.cpu(), torch.from_numpy(G[f'{case}_critic.{k}']), rtol=2e-3, atol=2e-4), k
+    tgt, _ = make_critic(O, units, n_critics, 62)
+    soft_update(c, tgt, 0.2)
+    for k, v in tgt.state_dict().items():
+        assert torch.allclose(v.cpu(), torch.from_numpy(G[f'{case}_target.{k}']), rtol=2e-3, atol=2e-4), k
