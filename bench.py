@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--minibatch', type=int, default=32768, help='minibatch rows per GPU')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo = rehearsal of the multi-rank path through host memory (ranks may share a GPU)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the multi-rank code path (process group, collectives) even with one rank: an RCCL rehearsal on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -103,7 +105,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    multi = world > 1
+    multi = world > 1 or args.force_dist
     if args.backend == 'gloo':
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -112,6 +114,9 @@ def main():
         import torch.distributed as dist
         from mineral_amd import parallel
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(dev))
         else:
@@ -177,6 +182,8 @@ def main():
                    'num_envs_total': args.num_envs * world, 'ms_per_update': 1e3 * dt / args.steps,
                    'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
     }
+    flat64 = agent.model.flat.double()
+    out['param_checksum'] = [float(flat64.sum().item()), float((flat64 * flat64).sum().item())]   # run-to-run / rank-count comparisons
     if multi:
         out['ranks_in_sync'] = in_sync
     if rank == 0:

@@ -471,6 +471,27 @@ def test_two_ranks_share_one_gpu_through_host_staged_gloo():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_group_matches_the_single_process_path():
+    """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
+    issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's
+    bit for bit (global statistics of one rank are its local ones)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ['--force-dist']):
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '4096',
+               '--no-kernel-timing', '--no-cpu-baseline'] + extra
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]))
+    assert outs[1]['ranks_in_sync'] is True
+    assert outs[0]['param_checksum'] == outs[1]['param_checksum']
+
+
+@pytest.mark.gpu
 def test_launcher_cli_trains_and_writes_the_reference_artifacts(tmp_path):
     """`python -m mineral.scripts.run task=Synthetic ...` (the drop-in launch line) trains for a few epochs on the HIP path
     and leaves the on-disk artefacts of mineral/scripts/run.py:34-41 and ppo.py:416-426."""
