@@ -785,82 +785,111 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     static_assert(TN == 1 && WGN == 1 && TM == 1, "heads use a 32-wide tile, one 32x32 block per wave");
     const HeadsP& hp = p.h;
     const int A = hp.act_dim;
-    const float bias = (l32 < Nv) ? p.bias[tw][l32] : 0.f;
     const bool actor = (tw + p.tw0 == 0);
-    float cs0 = 0.f, cs1 = 0.f;              // column sums of the seeds (bias gradients)
-    double macc[MRL_NMETRIC];
+    // The MFMA layout gives a lane 16 rows of ONE column, and only the first 2A columns mean anything.  The wave's tile
+    // goes through LDS once so that afterwards a lane owns (row, action) pairs: 16-lane groups take one row each (8
+    // rows per group), the per-row sums over actions stay 16-lane reductions, and the critic takes one row per lane.
+    constexpr int TS = 33;                                   // row stride of the transposed tile
+    constexpr int NPART = 16;                                // (wave, group) partials
+    float* T = lds + wave * (32 * TS);
+    double* red = reinterpret_cast<double*>(lds + 4 * 32 * TS);          // [NPART][MRL_NMETRIC]
+    float* csum = lds + 4 * 32 * TS + NPART * MRL_NMETRIC * 2;           // [NPART][32] column sums of the seeds
+    static_assert(4 * 32 * TS + NPART * MRL_NMETRIC * 2 + NPART * 32 <= LDS_ALL, "heads epilogue scratch");
+    {
+      const float bias = (l32 < Nv) ? p.bias[tw][l32] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MRL_NMETRIC; ++i) macc[i] = 0.0;
+      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + l32] = acc[0][0][r] + bias;
+      if constexpr (EPI == EPI_HEADS_TRAIN) {
+        for (int i = tid; i < NPART * MRL_NMETRIC; i += 256) red[i] = 0.0;
+        for (int i = tid; i < NPART * 32; i += 256) csum[i] = 0.f;
+      }
+    }
+    __syncthreads();
+    // hardware exp2 / log2 / rcp (about 1 ulp each) instead of the libm routines: the tolerances of the parity tests
+    // are three orders of magnitude wider
+    auto fexp = [](float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); };
+    auto flog = [](float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); };
+    auto frcp = [](float x) { return __builtin_amdgcn_rcpf(x); };
+    auto ftanh = [&](float x) {                              // 1 - 2 / (1 + e^{2|x|}), sign restored
+      const float e = __builtin_amdgcn_exp2f(2.88539008177792681472f * fabsf(x));
+      return copysignf(1.0f - 2.0f * frcp(1.0f + e), x);
+    };
+    const int wrow0 = m0 + wm * 32;                          // first row of this wave's tile
+    if (actor) {
+      // lanes j < A of a 16-lane group hold action j of the group's row: mu_head[j] and logstd[j]
+      // (mineral/agents/ppo/models.py:140-151)
+      const int g = lane >> 4, j = lane & 15;
+      const bool jv = j < A;
+      float cs0 = 0.f, cs1 = 0.f;                            // column sums of the seeds (bias gradients)
+      float m_al = 0.f, m_ent = 0.f, m_bl = 0.f, m_kl = 0.f, m_clip = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + rowof(0, r);
-      const bool rv = row < p.M;
-      const int rowc = rv ? row : 0;
-      float o = acc[0][0][r] + bias;
-      if (actor) {
-        // lanes j < A hold mu_head[j]; lanes A <= j < 2A hold logstd[j-A] (mineral/agents/ppo/models.py:140-151)
-        float ls = __shfl(o, (lane & 32) + ((l32 + A) & 31));
-        const bool jv = l32 < A;
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 4 + g;
+        const int row = wrow0 + lr;
+        const bool rv = row < p.M;
+        const int rowc = rv ? row : 0;
+        const float o = T[lr * TS + j];
+        const float ls = T[lr * TS + ((A + j) & 31)];
         float mu, sg = 0.f, sigma;
         if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
-          mu = tanhf(o);
-          sg = sigmoid_f(ls + 2.0f);
+          mu = ftanh(o);
+          sg = sigmoid_fast(ls + 2.0f);
           sigma = (hp.maxstd - hp.minstd) * sg + hp.minstd;
         } else if (hp.dist_type == DIST_SQUASHED) {  // mineral/nets/dist.py:39-43; minstd / maxstd carry the logstd clamp
           mu = o;
-          sigma = expf(fminf(fmaxf(ls, hp.minstd), hp.maxstd));
+          sigma = fexp(fminf(fmaxf(ls, hp.minstd), hp.maxstd));
         } else {                                   // mineral/nets/dist.py:32-34
           mu = o;
-          sigma = expf(ls);
+          sigma = fexp(ls);
         }
         if (!jv) { mu = 0.f; sigma = 1.f; }
-        const float logsig = logf(sigma);
+        const float logsig = flog(sigma);
+        const float rsig = frcp(sigma);
         if (EPI == EPI_HEADS_ACT && hp.dist_type == DIST_SQUASHED) {
           // rsample + log_prob of the tanh-squashed normal (mineral/nets/distributions.py:10-52, sac.py:118-136):
           // u = mu + sigma*eps, a = tanh(u), log p = sum_j [ log N(u_j) - 2*(log 2 - u_j - softplus(-2 u_j)) ]
-          const float eps = jv ? hp.noise[(int64_t)rowc * A + l32] : 0.f;
+          const float eps = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
           const float u = mu + sigma * eps;
-          const float a = tanhf(u);
-          const float d = u - mu;
+          const float a = ftanh(u);
           const float x2 = -2.0f * u;
-          const float sp = x2 > 20.0f ? x2 : log1pf(expf(x2));
-          float lp = jv ? (-(d * d) / (2.0f * sigma * sigma) - logsig - MRL_LOG_SQRT_2PI) - 2.0f * (0.69314718055994530942f - u - sp) : 0.f;
+          const float sp = x2 > 20.0f ? x2 : flog(1.0f + fexp(x2));
+          float lp = jv ? (-0.5f * eps * eps - logsig - MRL_LOG_SQRT_2PI) - 2.0f * (0.69314718055994530942f - u - sp) : 0.f;
           lp = group_sum16(lp);
           if (rv && jv) {
-            const int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + l32;
+            const int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + j;
             hp.act_out[o_idx] = a;
             hp.mu[o_idx] = ls;          // the raw log-std: the backward needs to know where the clamp was active
             hp.sigma[o_idx] = sigma;
           }
-          if (rv && l32 == 0) hp.neglogp_out[row] = lp;   // the log-probability itself
+          if (rv && j == 0) hp.neglogp_out[row] = lp;   // the log-probability itself
         } else if constexpr (EPI == EPI_HEADS_ACT) {
           // mineral/agents/ppo/models.py:115-117 with sample = mu + sigma * noise
-          float eps = jv ? hp.noise[(int64_t)rowc * A + l32] : 0.f;
-          float a = mu + sigma * eps;
-          float d = a - mu;
-          float nl = jv ? (d * d) / (2.0f * sigma * sigma) + logsig + MRL_LOG_SQRT_2PI : 0.f;
+          const float eps = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
+          const float a = mu + sigma * eps;
+          const float d = a - mu;
+          float nl = jv ? (d * d) * (0.5f * rsig * rsig) + logsig + MRL_LOG_SQRT_2PI : 0.f;
           nl = group_sum16(nl);
           if (rv && jv) {
-            int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + l32;
+            const int64_t o_idx = (int64_t)row * hp.out_rs + hp.out_off + j;
             hp.act_out[o_idx] = a;
             hp.mu[o_idx] = mu;
             hp.sigma[o_idx] = sigma;
-            if (hp.act_clamped) hp.act_clamped[(int64_t)row * A + l32] = fminf(fmaxf(a, -1.0f), 1.0f);
+            if (hp.act_clamped) hp.act_clamped[(int64_t)row * A + j] = fminf(fmaxf(a, -1.0f), 1.0f);
           }
-          if (rv && l32 == 0) hp.neglogp_out[row] = nl;
+          if (rv && j == 0) hp.neglogp_out[row] = nl;
         } else {
           // mineral/agents/ppo/models.py:93-107 and mineral/agents/ppo/ppo.py:277-303
-          float a = jv ? hp.actions[(int64_t)rowc * A + l32] : 0.f;
-          float omu = jv ? hp.mu[(int64_t)rowc * A + l32] : 0.f;
-          float osg = jv ? hp.sigma[(int64_t)rowc * A + l32] : 1.f;
-          float d = a - mu;
-          float var2 = 2.0f * sigma * sigma;
-          float nl = jv ? (d * d) / var2 + logsig + MRL_LOG_SQRT_2PI : 0.f;
+          const float a = jv ? hp.actions[(int64_t)rowc * A + j] : 0.f;
+          const float omu = jv ? hp.mu[(int64_t)rowc * A + j] : 0.f;
+          const float osg = jv ? hp.sigma[(int64_t)rowc * A + j] : 1.f;
+          const float d = a - mu;
+          const float rvar = rsig * rsig;
+          float nl = jv ? (d * d) * (0.5f * rvar) + logsig + MRL_LOG_SQRT_2PI : 0.f;
           float ent = jv ? 0.5f + MRL_LOG_SQRT_2PI + logsig : 0.f;
           float bl = 0.f, dbl = 0.f;
           if (jv) {
             if (hp.bounds_type == 0) {             // 'bound' (ppo.py:480-484)
-              float hi = fmaxf(mu - 1.1f, 0.f), lo = fminf(mu + 1.1f, 0.f);
+              const float hi = fmaxf(mu - 1.1f, 0.f), lo = fminf(mu + 1.1f, 0.f);
               bl = lo * lo + hi * hi;
               dbl = 2.0f * hi + 2.0f * lo;
             } else {                               // 'reg' (ppo.py:485-487)
@@ -870,24 +899,24 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           }
           float kl = 0.f;
           if (jv) {                                // ppo.py:492-498, p0 = new, p1 = stored
-            float dm = omu - mu;
-            kl = logf(osg / sigma + 1e-5f) + (sigma * sigma + dm * dm) / (2.0f * (osg * osg + 1e-5f)) - 0.5f;
+            const float dm = omu - mu;
+            kl = flog(osg * rsig + 1e-5f) + (sigma * sigma + dm * dm) * (0.5f * frcp(osg * osg + 1e-5f)) - 0.5f;
           }
           nl = group_sum16(nl);
           ent = group_sum16(ent);
           bl = group_sum16(bl);
           kl = group_sum16(kl);
-          float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
-          float ratio = expf(oldnl - nl);                        // ppo.py:455
-          float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
-          float rc = fminf(fmaxf(ratio, lo_r), hi_r);
-          float x1 = -(adv * ratio), x2 = -(adv * rc);
-          float al = fmaxf(x1, x2);
-          float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;
-          float dratio = (x1 > x2) ? -adv : (x1 < x2) ? -adv * inr : 0.5f * (-adv) + 0.5f * (-adv * inr);
-          float dnl = hp.inv_mb * dratio * (-ratio);
-          float dmu = dnl * (-d / (sigma * sigma)) + hp.bounds_coef * hp.inv_mb * dbl;
-          float dsig = dnl * (-(d * d) / (sigma * sigma * sigma) + 1.0f / sigma) - hp.entropy_coef * hp.inv_mb / sigma;
+          const float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
+          const float ratio = fexp(oldnl - nl);                  // ppo.py:455
+          const float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
+          const float rc = fminf(fmaxf(ratio, lo_r), hi_r);
+          const float x1 = -(adv * ratio), x2 = -(adv * rc);
+          const float al = fmaxf(x1, x2);
+          const float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;
+          const float dratio = (x1 > x2) ? -adv : (x1 < x2) ? -adv * inr : 0.5f * (-adv) + 0.5f * (-adv * inr);
+          const float dnl = hp.inv_mb * dratio * (-ratio);
+          const float dmu = dnl * (-d * rvar) + hp.bounds_coef * hp.inv_mb * dbl;
+          const float dsig = dnl * (-(d * d) * (rvar * rsig) + rsig) - hp.entropy_coef * hp.inv_mb * rsig;
           float s_mu, s_ls;
           if (hp.dist_type == DIST_DREAMERV3) {
             s_mu = dmu * (1.0f - mu * mu);
@@ -899,87 +928,102 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           if (rv) {
             float* sd = hp.seeds[0] + (int64_t)row * 32;
             if (jv) {
-              sd[l32] = s_mu;
-              sd[A + l32] = s_ls;
+              sd[j] = s_mu;
+              sd[A + j] = s_ls;
               cs0 += s_mu;
               cs1 += s_ls;
-              hp.mu[(int64_t)row * A + l32] = mu;              // experience.py:83-87 write-back
-              hp.sigma[(int64_t)row * A + l32] = sigma;
-            } else if (l32 >= 2 * A) {
-              sd[l32] = 0.f;
+              hp.mu[(int64_t)row * A + j] = mu;                // experience.py:83-87 write-back
+              hp.sigma[(int64_t)row * A + j] = sigma;
             }
-            if (l32 == 0) {
-              macc[0] += al;
-              macc[1] += ent;
-              macc[2] += bl;
-              macc[3] += kl;
-              macc[4] += (fabsf(ratio - 1.0f) > hp.e_clip) ? 1.0 : 0.0;
+            for (int c = 2 * A + j; c < 32; c += 16) sd[c] = 0.f;   // zero padding of the seed row
+            if (j == 0) {
+              m_al += al;
+              m_ent += ent;
+              m_bl += bl;
+              m_kl += kl;
+              m_clip += (fabsf(ratio - 1.0f) > hp.e_clip) ? 1.0f : 0.0f;
             }
           }
         }
-      } else {
-        // critic: lane 0 of each half holds the value (models.py:147-149)
-        if constexpr (EPI == EPI_HEADS_ACT) {
-          if (rv && l32 == 0) {
-            float v = o;
-            if (hp.vrms_mean) {                    // normalizers.py:70-73 (clamp first, then un-scale)
-              v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
-              v = sqrtf((float)hp.vrms_var[0] + hp.vrms_eps) * v + (float)hp.vrms_mean[0];
-            }
-            hp.value_out[row] = v;
-          }
-        } else {
-          float ret = hp.returns[rowc], vp = hp.value_preds[rowc];
+      }
+      if constexpr (EPI == EPI_HEADS_TRAIN) {
+        const int part = wave * 4 + g;
+        if (jv) {
+          csum[part * 32 + j] = cs0;
+          csum[part * 32 + A + j] = cs1;
+        }
+        if (j == 0) {
+          double* m = red + part * MRL_NMETRIC;
+          m[0] = (double)m_al; m[1] = (double)m_ent; m[2] = (double)m_bl; m[3] = (double)m_kl; m[4] = (double)m_clip;
+        }
+      }
+    } else {
+      // critic: column 0 of the tile is the value (models.py:147-149); lane l32 takes row l32, the two half-waves share
+      // the stores of the zero-padded seed row
+      const int lr = l32;
+      const int row = wrow0 + lr;
+      const bool rv = row < p.M;
+      const int rowc = rv ? row : 0;
+      const float o = T[lr * TS];
+      if constexpr (EPI == EPI_HEADS_ACT) {
+        if (rv && h == 0) {
           float v = o;
-          float e1 = v - ret;
-          float cl = e1 * e1, dv = 2.0f * e1;      // ppo.py:466-473
-          if (hp.clip_value_loss) {
-            float dvp = v - vp;
-            float vc = vp + fminf(fmaxf(dvp, -hp.e_clip), hp.e_clip);
-            float e2 = vc - ret;
-            float c2v = e2 * e2;
-            float in2 = (dvp >= -hp.e_clip && dvp <= hp.e_clip) ? 1.0f : 0.0f;
-            float d2 = 2.0f * e2 * in2;
-            dv = (cl > c2v) ? dv : (cl < c2v) ? d2 : 0.5f * dv + 0.5f * d2;
-            cl = fmaxf(cl, c2v);
+          if (hp.vrms_mean) {                    // normalizers.py:70-73 (clamp first, then un-scale)
+            v = fminf(fmaxf(v, p.clamp_lo), p.clamp_hi);
+            v = sqrtf((float)hp.vrms_var[0] + hp.vrms_eps) * v + (float)hp.vrms_mean[0];
           }
-          float s_v = hp.inv_mb * 0.5f * hp.critic_coef * dv;   // ppo.py:285
-          if (rv) {
-            float* sd = hp.seeds[1] + (int64_t)row * 32;
-            sd[l32] = (l32 == 0) ? s_v : 0.f;
-            if (l32 == 0) {
-              cs0 += s_v;
-              macc[5] += cl;
-              double dr = (double)ret - (double)v;
-              macc[6] += dr;
-              macc[7] += dr * dr;
-              macc[8] += ret;
-              macc[9] += (double)ret * ret;
-            }
-          }
+          hp.value_out[row] = v;
+        }
+      } else {
+        const float ret = hp.returns[rowc], vp = hp.value_preds[rowc];
+        const float v = o;
+        const float e1 = v - ret;
+        float cl = e1 * e1, dv = 2.0f * e1;      // ppo.py:466-473
+        if (hp.clip_value_loss) {
+          const float dvp = v - vp;
+          const float vc = vp + fminf(fmaxf(dvp, -hp.e_clip), hp.e_clip);
+          const float e2 = vc - ret;
+          const float c2v = e2 * e2;
+          const float in2 = (dvp >= -hp.e_clip && dvp <= hp.e_clip) ? 1.0f : 0.0f;
+          const float d2 = 2.0f * e2 * in2;
+          dv = (cl > c2v) ? dv : (cl < c2v) ? d2 : 0.5f * dv + 0.5f * d2;
+          cl = fmaxf(cl, c2v);
+        }
+        const float s_v = hp.inv_mb * 0.5f * hp.critic_coef * dv;   // ppo.py:285
+        if (rv) {
+          f32x4* sd = reinterpret_cast<f32x4*>(hp.seeds[1] + (int64_t)row * 32 + h * 16);
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          sd[0] = (h == 0) ? f32x4{s_v, 0.f, 0.f, 0.f} : z;
+          sd[1] = z; sd[2] = z; sd[3] = z;
+        }
+        const bool mine = rv && h == 0;
+        double dr = mine ? (double)ret - (double)v : 0.0;
+        double q[5] = {mine ? (double)cl : 0.0, dr, dr * dr, mine ? (double)ret : 0.0, mine ? (double)ret * ret : 0.0};
+        float cs = mine ? s_v : 0.f;
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) q[i] += __shfl_xor(q[i], msk);
+          cs += __shfl_xor(cs, msk);
+        }
+        if (lane == 0) {
+          double* m = red + (wave * 4) * MRL_NMETRIC;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) m[5 + i] = q[i];
+          csum[(wave * 4) * 32] = cs;
         }
       }
     }
     if constexpr (EPI == EPI_HEADS_TRAIN) {
-      double* red = reinterpret_cast<double*>(lds);     // [8][MRL_NMETRIC]
-      float* csum = lds + 256;                           // [8][64]
-      csum[(wave * 2 + h) * 64 + l32] = cs0;
-      csum[(wave * 2 + h) * 64 + 32 + l32] = cs1;
-      if (l32 == 0) {
-#pragma unroll
-        for (int i = 0; i < MRL_NMETRIC; ++i) red[(wave * 2 + h) * MRL_NMETRIC + i] = macc[i];
-      }
       __syncthreads();
       if (tid < MRL_NMETRIC) {
         double s = 0.0;
-        for (int w = 0; w < 8; ++w) s += red[w * MRL_NMETRIC + tid];
+        for (int w = 0; w < NPART; ++w) s += red[w * MRL_NMETRIC + tid];
         hp.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
       }
       if (tid < 32) {
-        const int src = actor ? (tid < A ? tid : (tid < 2 * A ? 32 + tid - A : -1)) : (tid == 0 ? 0 : -1);
         float s = 0.f;
-        if (src >= 0)
-          for (int w = 0; w < 8; ++w) s += csum[w * 64 + src];
+        for (int w = 0; w < NPART; ++w) s += csum[w * 32 + tid];
         hp.headb_part[((int64_t)blockIdx.x * 2 + tw) * 32 + tid] = s;
       }
     }
