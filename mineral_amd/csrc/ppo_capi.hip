@@ -121,6 +121,8 @@ extern "C" int mrl_param_offsets(const mrl_net* net, int64_t* offs, int32_t* n) 
 static inline int fwd_bm(int n) { return n == 512 ? 64 : 128; }   // rows per block of the full-row (LayerNorm) tiles
 // wide layers take the streaming LayerNorm backward: rows per block of that kernel
 static inline bool ln_bwd_streamed(int n) { return n >= 256; }
+// rows per block of the fused dgrad + LayerNorm backward of a narrow layer: 32-row tiles for small batches of the 128-wide layer
+static inline int fused_bwd_rows(int u, int64_t rows) { return (u == 128 && rows <= 8192) ? 32 : 128; }
 static inline int ln_bwd_rows(int64_t rows) { int64_t r = cdiv(rows, 512); return (int)(r < 4 ? 4 : cdiv(r, 4) * 4); }
 
 constexpr int MRL_LDS_PER_CU = 160 * 1024;   // gfx950
@@ -169,7 +171,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
       w->rstd[tw][l] = o; o = align64(o + rows_pad);
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
-      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, 128);
+      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
@@ -1114,9 +1116,14 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.M = (int)mb; p.N = u; p.K = kdim;
     if (ln_bwd_streamed(u)) {
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
-      p.ksplit = kdim; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = u / 128;
-      p.n_groups = p.m_tiles; p.group_mode = 0;
-      launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+      p.ksplit = kdim; p.n_tiles = u / 128; p.group_mode = 0;
+      if (mb <= MRL_SMALL_M) {   // 32-row tiles: four times the blocks for a batch that would leave most CUs idle
+        p.m_tiles = (int)cdiv(mb, 32); p.n_groups = p.m_tiles;
+        launch_gemm<32, 128, 16, 1, 4, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+      } else {
+        p.m_tiles = (int)cdiv(mb, 128); p.n_groups = p.m_tiles;
+        launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+      }
       LnBwdArgs a;
       memset(&a, 0, sizeof(a));
       for (int k = 0; k < towers; ++k) {
@@ -1131,7 +1138,9 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     } else {
       // narrow layers (<= 128 wide): the whole row fits one block's accumulators, LayerNorm backward fused
       const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
-      if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      if (u == 128 && fused_bwd_rows(u, mb) == 32)
+        launch_gemm<32, 128, 16, 1, 4, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, dim3((unsigned)cdiv(p.M, 32), 1, towers), s);
+      else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
       else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
       else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
     }
