@@ -429,7 +429,10 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
     for (int im = 0; im < TM; ++im)
 #pragma unroll
       for (int in = 0; in < TN; ++in)
-        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
+        if constexpr (EPI == EPI_LNFWD)   // transposed product: a lane holds one batch row and 16 features per 32x32 tile
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[in][j], af[im][j], acc[im][in], 0, 0, 0);
+        else
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
   };
   auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
 #pragma unroll
@@ -524,116 +527,85 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
         }
       }
   } else if constexpr (EPI == EPI_LNFWD) {
+    // The forward kernels issue their MFMAs with the operands swapped, so lane (l32, h) of tile (im, in) holds batch row
+    // wm*TM*32 + im*32 + l32 and the 16 features wn*TN*32 + in*32 + 8*g + 4*h + (0..3), g = 0..3: the LayerNorm sums
+    // over a row are plain adds in the lane plus one exchange between the half-waves, and every 4 consecutive
+    // accumulator registers leave as one 16-byte store.
     // work on scalars from here on: element-wise updates of the 16-wide accumulator vectors cost whole-vector copies
     float ea[TM][TN][16];
+    const float* bias = p.bias[tw];
 #pragma unroll
-    for (int im = 0; im < TM; ++im)
+    for (int in = 0; in < TN; ++in)
 #pragma unroll
-      for (int in = 0; in < TN; ++in)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wn * TN * 32 + in * 32 + 8 * g + 4 * h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ea[im][in][r] = acc[im][in][r];
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ea[im][in][g * 4 + e] = acc[im][in][g * 4 + e] + b4[e];
+      }
     // bias, two-pass LayerNorm statistics over the full row (BN == N), store xhat and rstd
     float* partA = lds;                 // [WGN][BM] row sums per wave column
     float* partB = lds + BM * WGN;      // [WGN][BM] sums of squared deviations
-    const float* bias = p.bias[tw];
-#pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      float b = bias[n0 + colof(in)];
-#pragma unroll
-      for (int im = 0; im < TM; ++im)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ea[im][in][r] += b;
-    }
     const float invn = 1.0f / (float)BN;
-    // after a 16-value halving reduction lane pair (2k, 2k+1) holds the total of value k of its half-wave
-    const int own = l32 >> 1;
-    const int own_row = wm * TM * 32 + (own & 3) + 8 * (own >> 2) + 4 * h;   // + im*32
-    const bool owner = (l32 & 1) == 0;
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
-      float sv[16];
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = 0.f;
+      for (int in = 0; in < TN; ++in)
 #pragma unroll
-        for (int in = 0; in < TN; ++in) t += ea[im][in][r];
-        sv[r] = t;
-      }
-      const float tot = halving_sum32<16>(sv, l32);
-      if (owner) partA[wn * BM + own_row + im * 32] = tot;
+        for (int r = 0; r < 16; r += 4) {
+          t0 += ea[im][in][r]; t1 += ea[im][in][r + 1]; t2 += ea[im][in][r + 2]; t3 += ea[im][in][r + 3];
+        }
+      float t = (t0 + t1) + (t2 + t3);
+      t += __shfl_xor(t, 32);
+      if (h == 0) partA[wn * BM + wm * TM * 32 + im * 32 + l32] = t;
     }
     MRL_KT(1003);
     __syncthreads();
     MRL_KT(1004);
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
-      float qv[16];
+      const int row = wm * TM * 32 + im * 32 + l32;
+      float m = partA[row];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
-        f32x4 t = *reinterpret_cast<const f32x4*>(partA + base);
+      for (int w = 1; w < WGN; ++w) m += partA[w * BM + row];
+      const float mean = m * invn;
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
-        for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partA + w * BM + base);
+      for (int in = 0; in < TN; ++in)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float mean = t[rr] * invn;
-          float sq = 0.f;
-#pragma unroll
-          for (int in = 0; in < TN; ++in) {
-            float d = ea[im][in][g * 4 + rr] - mean;
-            ea[im][in][g * 4 + rr] = d;
-            sq += d * d;
-          }
-          qv[g * 4 + rr] = sq;
+        for (int r = 0; r < 16; r += 4) {
+          const float d0 = ea[im][in][r] - mean, d1 = ea[im][in][r + 1] - mean, d2 = ea[im][in][r + 2] - mean, d3 = ea[im][in][r + 3] - mean;
+          ea[im][in][r] = d0; ea[im][in][r + 1] = d1; ea[im][in][r + 2] = d2; ea[im][in][r + 3] = d3;
+          q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
         }
-      }
-      const float tot = halving_sum32<16>(qv, l32);
-      if (owner) partB[wn * BM + own_row + im * 32] = tot;
+      float q = (q0 + q1) + (q2 + q3);
+      q += __shfl_xor(q, 32);
+      if (h == 0) partB[wn * BM + row] = q;
     }
     MRL_KT(1005);
     __syncthreads();
     MRL_KT(1006);
-    // xhat leaves through a per-wave LDS transpose: the accumulator layout (one column, 16 rows per lane) would need
-    // one 4-byte store per element; 32 x XW sub-blocks are rewritten row-major in LDS and stored 16 bytes per lane
-    // (rows >= M of the last block are written too: the activation workspace is padded to whole row tiles)
-    constexpr int XI = TN >= 2 ? 2 : 1, XW = 32 * XI, XS = XW + 8;   // row stride = 8 mod 16 floats: conflict-free writes
-    static_assert(2 * BM * WGN + 4 * 32 * XS <= LDS_ALL, "LDS too small for the store transpose");
-    static_assert(TN % XI == 0, "column blocks are transposed in pairs");
-    float* xs = lds + 2 * BM * WGN + wave * 32 * XS;
+    // rows >= M of the last block are written too: the activation workspace is padded to whole row tiles
     float* outp = p.out[tw] + (int64_t)m0 * BN;
     float* rs = p.rstd[tw];
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
-      float rstd_r[16];
+      const int row = wm * TM * 32 + im * 32 + l32;
+      float v = partB[row];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int base = wm * TM * 32 + im * 32 + 8 * g + 4 * h;
-        f32x4 t = *reinterpret_cast<const f32x4*>(partB + base);
+      for (int w = 1; w < WGN; ++w) v += partB[w * BM + row];
+      const float rstd = 1.0f / sqrtf(v * invn + p.ln_eps);
+      if (wn == 0 && h == 0) rs[m0 + row] = rstd;
+      float* orow = outp + (int64_t)row * BN + wn * TN * 32 + 4 * h;
 #pragma unroll
-        for (int w = 1; w < WGN; ++w) t += *reinterpret_cast<const f32x4*>(partB + w * BM + base);
+      for (int in = 0; in < TN; ++in)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float rstd = 1.0f / sqrtf(t[rr] * invn + p.ln_eps);
-          rstd_r[g * 4 + rr] = rstd;
-          if (wn == 0 && l32 == 0) rs[m0 + base + rr] = rstd;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o4 = {ea[im][in][g * 4] * rstd, ea[im][in][g * 4 + 1] * rstd, ea[im][in][g * 4 + 2] * rstd, ea[im][in][g * 4 + 3] * rstd};
+          *reinterpret_cast<f32x4*>(orow + in * 32 + 8 * g) = o4;
         }
-      }
-#pragma unroll
-      for (int ip = 0; ip < TN; ip += XI) {
-#pragma unroll
-        for (int i2 = 0; i2 < XI; ++i2)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            xs[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + i2 * 32 + l32] = ea[im][ip + i2][r] * rstd_r[r];
-        // same wave wrote and reads: LDS executes a wave's operations in order
-        const int row0 = wm * TM * 32 + im * 32, col0 = wn * TN * 32 + ip * 32;
-#pragma unroll
-        for (int q = 0; q < 32 * XW / 4 / 64; ++q) {
-          const int idx = q * 64 + lane, row = idx / (XW / 4), ch = idx % (XW / 4);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xs + row * XS + ch * 4);
-          *reinterpret_cast<f32x4*>(outp + (int64_t)(row0 + row) * BN + col0 + ch * 4) = v;
-        }
-      }
     }
   } else if constexpr (EPI == EPI_LNBWD) {
     // work on scalars from here on: element-wise updates of the 16-wide accumulator vectors cost whole-vector copies

@@ -332,7 +332,7 @@ constexpr int MRL_SMALL_M = 8192;
       const dim3 g_((unsigned)cdiv(p.M, 32), 1, towers);                                                                  \
       switch (N) {                                                                                                        \
         case 512: launch_gemm<32, 512, 16, 1, 4, LA, LB, EPI, PRO, 1>(p, g_, s); break;                                   \
-        case 256: launch_gemm<32, 256, 16, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                      \
+        case 256: launch_gemm<32, 256, 32, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                      \
         case 128: launch_gemm<32, 128, BKBIG, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                   \
         case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
         default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
