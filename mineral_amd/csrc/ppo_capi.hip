@@ -604,21 +604,37 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
   }
 }
 
-__global__ void moments_final_kernel(const double* __restrict__ part, int chunks, int cols, double n, int correction,
-                                     float* __restrict__ mean_out, float* __restrict__ var_out) {
-  int c = threadIdx.x + blockIdx.x * blockDim.x;
-  int64_t g = blockIdx.y;
-  if (c >= cols) return;
+// One block per group and per 256 columns: 256 / cols thread rows walk the chunk partials side by side and are combined
+// in a fixed order through LDS (one thread per column walking all the chunks costs a dependent load per chunk).
+__global__ __launch_bounds__(256) void moments_final_kernel(const double* __restrict__ part, int chunks, int cols, double n, int correction,
+                                                            float* __restrict__ mean_out, float* __restrict__ var_out) {
+  __shared__ double smd[2][256];
+  const int bc = cols < 256 ? cols : 256;          // columns of this block
+  const int lanes = 256 / bc;                      // thread rows over the chunks
+  const int cl = threadIdx.x % bc, rl = threadIdx.x / bc;
+  const int c = blockIdx.x * 256 + cl;
+  const int64_t g = blockIdx.y;
   double s = 0, s2 = 0;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const double* o = part + ((g * chunks + ch) * 2) * cols;
-    s += o[c];
-    s2 += o[cols + c];
+  if (rl < lanes && c < cols) {
+    for (int ch = rl; ch < chunks; ch += lanes) {
+      const double* o = part + ((g * chunks + ch) * 2) * cols;
+      s += o[c];
+      s2 += o[cols + c];
+    }
   }
-  double m = s / n;
-  double v = (s2 - s * s / n) / (n - (double)correction);
-  mean_out[g * cols + c] = (float)m;
-  var_out[g * cols + c] = (float)(v > 0 ? v : 0.0);
+  smd[0][threadIdx.x] = s;
+  smd[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    for (int i = 1; i < lanes; ++i) {
+      s += smd[0][i * bc + cl];
+      s2 += smd[1][i * bc + cl];
+    }
+    double m = s / n;
+    double v = (s2 - s * s / n) / (n - (double)correction);
+    mean_out[g * cols + c] = (float)m;
+    var_out[g * cols + c] = (float)(v > 0 ? v : 0.0);
+  }
 }
 
 __global__ void rms_merge_kernel(double* mean, double* var, double* count, const float* __restrict__ bmean,
@@ -1052,7 +1068,7 @@ extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int
   size_t smem = (size_t)2 * rowlanes * cols * sizeof(double);
   hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), smem, s, x, cols, group_rows,
                      chunk_rows, (double*)workspace);
-  hipLaunchKernelGGL(moments_final_kernel, dim3((cols + 63) / 64, (unsigned)groups), dim3(64), 0, s, (const double*)workspace,
+  hipLaunchKernelGGL(moments_final_kernel, dim3((cols + 255) / 256, (unsigned)groups), dim3(256), 0, s, (const double*)workspace,
                      (int)chunks, cols, (double)group_rows, correction, mean_out, var_out);
   MRL_CHECK_LAUNCH("mrl_batch_moments");
   return MRL_OK;
