@@ -24,8 +24,9 @@ class EnsembleCritic(_Flat):
     def __init__(self, state_dim, action_dim=None, n_critics=1, n_sample=None, with_vmap=False, mlp_kwargs=None, weight_init='orthogonal', device='cuda'):
         _hip.lib()
         units = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'EnsembleCritic')
-        if n_critics not in (1, 2) or n_sample is not None or with_vmap or weight_init != 'orthogonal':
-            raise NotImplementedError('the HIP critic ensemble has n_critics in {1, 2}, n_sample=None, with_vmap=False, weight_init=orthogonal')
+        if n_critics not in (1, 2) or n_sample is not None or with_vmap or weight_init not in ('orthogonal', 'orthogonalg1'):
+            raise NotImplementedError('the HIP critic ensemble has n_critics in {1, 2}, n_sample=None, with_vmap=False, '
+                                      'weight_init in {orthogonal, orthogonalg1}')
         if not str(device).startswith('cuda'):
             raise _hip.HipLibraryError(f'the critic runs on an MI355X only (device={device}); no CPU fallback')
         self.net = _hip.make_critic_net(int(state_dim), int(n_critics), units)
@@ -37,8 +38,24 @@ class EnsembleCritic(_Flat):
             parts += [[(f'critics.{c}.mlp.{b}.weight', (1, units[-1]))], [(f'critics.{c}.mlp.{b}.bias', (1,))]]
         super().__init__(self.net, None, parts, device)
         self.units, self.n_critics, self.state_dim = units, int(n_critics), int(state_dim)
+        self.weight_init = weight_init
         self._ws = None
         self.reset_parameters()
+
+    def reset_parameters(self):
+        """models.py:10-14,72-78,226-233: orthogonal Linear weights with gain sqrt(2) ('orthogonal') or 1 ('orthogonalg1'), zero
+        biases; LayerNorm keeps torch's default (ones / zeros)."""
+        gain = 1.4142135623730951 if self.weight_init == 'orthogonal' else 1.0
+        with torch.no_grad():
+            for name, v in self._views.items():
+                if name.endswith('.weight') and v.dim() == 2:
+                    w = torch.empty(v.shape, dtype=torch.float32)
+                    torch.nn.init.orthogonal_(w, gain=gain)
+                    v.copy_(w)
+                elif name.endswith('.weight'):
+                    v.fill_(1.0)
+                else:
+                    v.zero_()
 
     @staticmethod
     def _query(net, which):
