@@ -112,6 +112,16 @@ int mrl_policy_act(const mrl_net* net, const float* params, const mrl_rms* obs_r
                    const float* obs, const float* noise, int32_t t, const mrl_rollout* buf, float* actions_clamped,
                    float* last_values, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Metrics.update of one env step (mineral/common/metrics.py:59-67, mineral/common/tracker.py:10-30; callers
+ * ppo.py:165-167, sac.py:163-165) without the reference's host round trip (`torch.where(dones)[0].tolist()`):
+ * cur_rewards += rewards, cur_lengths += 1; the finished episodes (dones != 0, in env order) are appended to the two
+ * rings that hold the last `window` finished episodes (oldest entries fall out), *head advances, *num_episodes grows,
+ * and the finished envs' running reward / length restart at 0.  dones: num_envs bytes (bool / uint8).
+ * ring_rewards / ring_lengths: `window` doubles each (the trackers' deques); head, num_episodes: one int64 each. */
+int mrl_episode_update(const float* rewards, const uint8_t* dones, int64_t num_envs, float* cur_rewards,
+                       int64_t* cur_lengths, double* ring_rewards, double* ring_lengths, int32_t window, int64_t* head,
+                       int64_t* num_episodes, void* stream);
+
 /* Reward shaping + time-out bootstrap + done flags of one step (ppo.py:153-163, reward_shaper.py:10-15):
  * rewards_tn[t] = r*scale (+ gamma*values_tn[t]*time_outs), dones_tn[t] = dones.  time_outs may be NULL. */
 int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,

@@ -2,70 +2,71 @@
 
 The reference pulls `torch.where(dones)[0].tolist()` to the host after every env step
 (mineral/agents/ppo/ppo.py:165).  Here the per-env running reward / length and the window of the last
-`tracker_len` finished episodes stay on the device; the host reads them once per epoch when the means are
-logged.  Window contents are identical: finished episodes enter in env order, oldest entries fall out.
+`tracker_len` finished episodes stay on the device and one kernel (`mrl_episode_update`) does the whole update of an env
+step; the host reads the window once per epoch when the means are logged.  Window contents are identical: finished
+episodes enter in env order, oldest entries fall out.
 """
 
+import ctypes as C
+
 import torch
+
+from .. import _hip
 
 
 class DeviceTracker:
     """deque(maxlen=L) of floats on the device, initialised with zeros like tracker.py:19."""
 
-    def __init__(self, max_len, device):
+    def __init__(self, max_len, device, head=None):
         self.max_len = max_len
-        self.ring = torch.zeros(max_len + 1, dtype=torch.float64, device=device)   # slot L is a dump slot
-        self.head = torch.zeros((), dtype=torch.int64, device=device)
-
-    def push_masked(self, values, mask, rank_from_end, count):
-        """Append values[mask] in index order; rank_from_end = number of masked entries after each element."""
-        L = self.max_len
-        keep = mask & (rank_from_end < L)
-        kept = torch.clamp(count, max=L)
-        # position of each kept element: head + (kept - 1 - rank_from_end)
-        pos = (self.head + kept - 1 - rank_from_end) % L
-        pos = torch.where(keep, pos, torch.full_like(pos, L))
-        self.ring.index_put_((pos,), values.to(torch.float64))
-        self.head = (self.head + kept) % L
+        self.ring = torch.zeros(max_len, dtype=torch.float64, device=device)
+        self.head = head if head is not None else torch.zeros(1, dtype=torch.int64, device=device)
 
     def mean(self):
-        return float(self.ring[: self.max_len].mean().item())
+        return float(self.ring.mean().item())
 
     @property
     def window(self):
-        L = self.max_len
         h = int(self.head.item())
-        r = self.ring[:L].tolist()
+        r = self.ring.tolist()
         return r[h:] + r[:h]
 
 
 class Metrics:
     def __init__(self, current_scores, tracker_len, info_keys=None, save_video_every=0, save_video_consecutive=0,
                  env_render=False):
+        _hip.lib()
         self.current_scores = current_scores
         dev = current_scores['rewards'].device
+        if dev.type != 'cuda':
+            raise _hip.HipLibraryError(f'episode metrics live on the MI355X (device={dev}); no CPU fallback')
+        if current_scores['rewards'].dtype != torch.float32 or current_scores['lengths'].dtype != torch.int64:
+            raise ValueError('current_scores: rewards float32, lengths int64')
         self.tracker_len = tracker_len
-        self.episode_trackers = {'rewards': DeviceTracker(tracker_len, dev), 'lengths': DeviceTracker(tracker_len, dev)}
-        self._num_episodes = torch.zeros((), dtype=torch.int64, device=dev)
+        rewards = DeviceTracker(tracker_len, dev)
+        self.episode_trackers = {'rewards': rewards, 'lengths': DeviceTracker(tracker_len, dev, head=rewards.head)}
+        self._num_episodes = torch.zeros(1, dtype=torch.int64, device=dev)
 
     @property
     def num_episodes(self):
         return int(self._num_episodes.item())
 
     def update(self, epoch, env, obs, rewards, dones, extras=None):
-        """`dones` is the (N,) bool tensor itself (no index list, no sync)."""
+        """`dones` is the (N,) tensor itself (no index list, no sync)."""
         cs = self.current_scores
-        cs['rewards'] += rewards
-        cs['lengths'] += 1
-        d = dones.to(torch.bool)
-        d64 = d.to(torch.int64)
-        count = d64.sum()
-        rank_from_end = count - torch.cumsum(d64, 0)
-        self.episode_trackers['rewards'].push_masked(cs['rewards'], d, rank_from_end, count)
-        self.episode_trackers['lengths'].push_masked(cs['lengths'], d, rank_from_end, count)
-        self._num_episodes += count
-        cs['rewards'].masked_fill_(d, 0)
-        cs['lengths'].masked_fill_(d, 0)
+        n = cs['rewards'].numel()
+        r = rewards.reshape(-1).to(torch.float32).contiguous()
+        d = dones.reshape(-1)
+        if d.dtype not in (torch.bool, torch.uint8):
+            d = d != 0
+        d = d.contiguous()
+        if r.numel() != n or d.numel() != n:
+            raise ValueError(f'metrics.update: {r.numel()} rewards / {d.numel()} dones for {n} envs')
+        t = self.episode_trackers
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _hip.check(_hip.lib().mrl_episode_update(_hip.ptr(r), _hip.ptr(d), n, _hip.ptr(cs['rewards']), _hip.ptr(cs['lengths']), _hip.ptr(t['rewards'].ring),
+                                                 _hip.ptr(t['lengths'].ring), self.tracker_len, _hip.ptr(t['rewards'].head), _hip.ptr(self._num_episodes),
+                                                 stream), 'mrl_episode_update')
 
     def flush_video(self, epoch):
         return

@@ -440,6 +440,64 @@ __global__ void rms_to_f32_kernel(const double* mean, const double* var, float e
   }
 }
 
+// Episode bookkeeping of one env step in one launch (one block): wave w walks a contiguous segment of the envs 64 at a
+// time (coalesced), finished episodes are ranked in env order with ballots + a scan over the 16 wave counts, and enter
+// the rings at (head + kept - 1 - rank_from_end) mod window exactly like appends to a deque(maxlen=window).
+__global__ __launch_bounds__(1024) void episode_update_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones, int64_t n,
+                                                              float* __restrict__ cur_r, int64_t* __restrict__ cur_l, double* __restrict__ ring_r,
+                                                              double* __restrict__ ring_l, int window, int64_t* __restrict__ head,
+                                                              int64_t* __restrict__ num_episodes) {
+  __shared__ int64_t wave_base[17];
+  __shared__ int wave_cnt[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per_wave = ((n + 15) / 16 + 63) / 64 * 64;
+  const int64_t w0 = wave * per_wave, w1 = (w0 + per_wave < n) ? w0 + per_wave : n;
+  int cnt = 0;
+  for (int64_t base = w0; base < w1; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < w1;
+    const bool d = valid && dones[i] != 0;
+    if (valid) {
+      cur_r[i] += rewards[i];
+      cur_l[i] += 1;
+    }
+    cnt += __popcll(__ballot(d));
+  }
+  if (lane == 0) wave_cnt[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int w = 0; w < 16; ++w) { wave_base[w] = run; run += wave_cnt[w]; }
+    wave_base[16] = run;
+  }
+  __syncthreads();
+  const int64_t total = wave_base[16], L = window, h0 = head[0];
+  const int64_t kept = total < L ? total : L;
+  int64_t run = wave_base[wave];
+  for (int64_t base = w0; base < w1; base += 64) {
+    const int64_t i = base + lane;
+    const bool d = i < w1 && dones[i] != 0;
+    const unsigned long long m = __ballot(d);
+    if (d) {
+      const int64_t k = run + __popcll(m & ((1ull << lane) - 1ull));
+      const int64_t rank_from_end = total - 1 - k;
+      if (rank_from_end < L) {
+        const int64_t pos = (h0 + kept - 1 - rank_from_end) % L;
+        ring_r[pos] = (double)cur_r[i];
+        ring_l[pos] = (double)cur_l[i];
+      }
+      cur_r[i] = 0.f;
+      cur_l[i] = 0;
+    }
+    run += __popcll(m);
+  }
+  __syncthreads();   // every thread has read head[0]
+  if (threadIdx.x == 0) {
+    head[0] = (h0 + kept) % L;
+    num_episodes[0] += total;
+  }
+}
+
 __global__ void rollout_write_kernel(float* __restrict__ rewards_t, uint8_t* __restrict__ dones_t,
                                      const float* __restrict__ values_t, const float* __restrict__ r,
                                      const uint8_t* __restrict__ dones, const uint8_t* __restrict__ time_outs, int64_t n,
@@ -1032,6 +1090,16 @@ extern "C" int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, dou
                      buf->returns, stats_out, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
                      value_rms ? value_rms->clamp_hi : 0.f);
   MRL_CHECK_LAUNCH("mrl_gae_normalize");
+  return MRL_OK;
+}
+
+extern "C" int mrl_episode_update(const float* rewards, const uint8_t* dones, int64_t num_envs, float* cur_rewards, int64_t* cur_lengths,
+                                  double* ring_rewards, double* ring_lengths, int32_t window, int64_t* head, int64_t* num_episodes, void* stream) {
+  if (!rewards || !dones || !cur_rewards || !cur_lengths || !ring_rewards || !ring_lengths || !head || !num_episodes) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (num_envs < 1 || window < 1) MRL_FAIL(MRL_EINVAL, "num_envs %lld, window %d", (long long)num_envs, window);
+  hipLaunchKernelGGL(episode_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, dones, num_envs, cur_rewards, cur_lengths,
+                     ring_rewards, ring_lengths, window, head, num_episodes);
+  MRL_CHECK_LAUNCH("mrl_episode_update");
   return MRL_OK;
 }
 

@@ -471,6 +471,42 @@ def test_two_ranks_share_one_gpu_through_host_staged_gloo():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,L', [(37, 10), (4096, 100), (70001, 100), (5, 8)])
+def test_device_metrics_window_equals_deque_semantics(N, L):
+    """mineral/common/metrics.py:59-67 + tracker.py through `mrl_episode_update`: window of the last L finished episodes, env
+    order, counts and running scores, against a deque on the host."""
+    import collections
+    from mineral_amd.common.metrics import Metrics
+    scores = {'rewards': torch.zeros(N, device=DEV), 'lengths': torch.zeros(N, dtype=torch.int64, device=DEV)}
+    m = Metrics(scores, L)
+    ref_r, ref_l = collections.deque([0] * L, maxlen=L), collections.deque([0] * L, maxlen=L)
+    cur_r, cur_l = np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.int64)
+    rng = np.random.RandomState(0)
+    total = 0
+    for step in range(40):
+        r = rng.randn(N).astype(np.float32)
+        p = 0.9 if step == 17 else (0.0 if step == 5 else 0.15)   # one step finishes more episodes than the window holds, one none
+        d = rng.rand(N) < p
+        dt = torch.from_numpy(d).to(DEV)
+        if step % 3 == 1:
+            dt = dt.float()                                        # envs may hand over float / integer done flags
+        m.update(0, None, None, torch.from_numpy(r).to(DEV), dt)
+        cur_r = (cur_r + r).astype(np.float32)
+        cur_l += 1
+        idx = np.nonzero(d)[0]
+        ref_r.extend(cur_r[idx].tolist())
+        ref_l.extend(cur_l[idx].tolist())
+        cur_r[idx] = 0
+        cur_l[idx] = 0
+        total += len(idx)
+    assert m.num_episodes == total
+    assert m.episode_trackers['rewards'].window == [float(x) for x in ref_r]          # same fp32 running sums, bit for bit
+    assert [int(x) for x in m.episode_trackers['lengths'].window] == list(ref_l)
+    assert np.array_equal(scores['rewards'].cpu().numpy(), cur_r) and np.array_equal(scores['lengths'].cpu().numpy(), cur_l)
+    assert abs(m.episode_trackers['rewards'].mean() - float(np.mean(ref_r))) < 1e-6
+
+
+@pytest.mark.gpu
 def test_one_rank_rccl_group_matches_the_single_process_path():
     """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
     issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's

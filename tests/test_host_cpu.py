@@ -104,35 +104,6 @@ def test_schedulers_match_reference_tables(golden):
     assert np.array_equal(np.array(cos), g['cos_lrs'])
 
 
-def test_device_metrics_window_equals_deque_semantics():
-    """mineral/common/metrics.py:59-67 + tracker.py: window of the last L finished episodes, env order, no sync."""
-    from mineral_amd.common.metrics import Metrics
-    N, L = 37, 10
-    scores = {'rewards': torch.zeros(N), 'lengths': torch.zeros(N, dtype=torch.int64)}
-    m = Metrics(scores, L)
-    ref_r, ref_l = collections.deque([0] * L, maxlen=L), collections.deque([0] * L, maxlen=L)
-    cur_r, cur_l = np.zeros(N), np.zeros(N, dtype=np.int64)
-    rng = np.random.RandomState(0)
-    total = 0
-    for step in range(40):
-        r = torch.from_numpy(rng.randn(N).astype(np.float32))
-        p = 0.9 if step == 17 else 0.15      # one step finishes more episodes than the window holds
-        d = torch.from_numpy(rng.rand(N) < p)
-        m.update(0, None, None, r, d)
-        cur_r += r.numpy().astype(np.float64)
-        cur_l += 1
-        idx = np.nonzero(d.numpy())[0]
-        ref_r.extend(np.float32(cur_r[idx]).tolist())
-        ref_l.extend(cur_l[idx].tolist())
-        cur_r[idx] = 0
-        cur_l[idx] = 0
-        total += len(idx)
-    assert m.num_episodes == total
-    np.testing.assert_allclose(m.episode_trackers['rewards'].window, list(ref_r), rtol=1e-5, atol=1e-6)
-    assert [int(x) for x in m.episode_trackers['lengths'].window] == list(ref_l)
-    assert abs(m.episode_trackers['rewards'].mean() - float(np.mean(ref_r))) < 1e-5
-
-
 def test_config_tree_access_patterns():
     from mineral_amd.config import Config
     c = Config.wrap({'agent': {'ppo': {'e_clip': 0.2, 'optim_kwargs': {'lr': 5e-4}}}, 'x': [1, {'y': 2}]})
