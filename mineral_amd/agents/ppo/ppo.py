@@ -138,7 +138,7 @@ class PPO(Agent):
         # --- Timing (ppo.py:109-113), with a device sync at scope ends ---
         self.timer = Timer(sync=lambda: torch.cuda.synchronize(dev))
         self.timer.wrap('agent', self, ['play_steps', 'train_epoch'])
-        self.timer.wrap('env', self.env, ['step'])
+        self.timer.wrap('env', self.env, ['step'], sync=False)   # per env step: host time only
         self.timer_total_names = ('agent.play_steps', 'agent.train_epoch')
 
         # --- Multi-GPU (ppo.py:115-123): no wrapper objects; see _sync_* below ---

@@ -144,7 +144,7 @@ class SAC(Agent):
         self.timer = Timer(sync=lambda: torch.cuda.synchronize(dev))
         self.timer.wrap('agent', self, ['explore_env', 'update_net'])
         self.timer.wrap('memory', self.memory, ['add_to_buffer'])
-        self.timer.wrap('env', self.env, ['step'])
+        self.timer.wrap('env', self.env, ['step'], sync=False)   # per env step: host time only
         self.timer_total_names = ('agent.explore_env', 'memory.add_to_buffer', 'agent.update_net')
 
     # ---------------------------------------------------------------------------------------------------------------

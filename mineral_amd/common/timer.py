@@ -22,18 +22,20 @@ class Timer:
         self._step = 0
 
     @contextlib.contextmanager
-    def scope(self, name):
-        if self._sync:
+    def scope(self, name, sync=True):
+        """sync=False times the host side only, like the reference: for scopes entered once per env step, where a device
+        sync at both ends would stop the host from running ahead of the device."""
+        if self._sync and sync:
             self._sync()
         t0 = time.perf_counter()
         yield
-        if self._sync:
+        if self._sync and sync:
             self._sync()
         self._durations[name].append(time.perf_counter() - t0)
 
-    def wrap(self, name, obj, methods):
+    def wrap(self, name, obj, methods, sync=True):
         for method in methods:
-            setattr(obj, method, self.scope(f'{name}.{method}')(getattr(obj, method)))
+            setattr(obj, method, self.scope(f'{name}.{method}', sync=sync)(getattr(obj, method)))
 
     def start(self, name):
         if name in self._open:
