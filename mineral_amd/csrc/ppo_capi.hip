@@ -440,60 +440,108 @@ __global__ void rms_to_f32_kernel(const double* mean, const double* var, float e
   }
 }
 
-// Episode bookkeeping of one env step in one launch (one block): wave w walks a contiguous segment of the envs 64 at a
-// time (coalesced), finished episodes are ranked in env order with ballots + a scan over the 16 wave counts, and enter
-// the rings at (head + kept - 1 - rank_from_end) mod window exactly like appends to a deque(maxlen=window).
-__global__ __launch_bounds__(1024) void episode_update_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones, int64_t n,
-                                                              float* __restrict__ cur_r, int64_t* __restrict__ cur_l, double* __restrict__ ring_r,
-                                                              double* __restrict__ ring_l, int window, int64_t* __restrict__ head,
-                                                              int64_t* __restrict__ num_episodes) {
-  __shared__ int64_t wave_base[17];
-  __shared__ int wave_cnt[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t per_wave = ((n + 15) / 16 + 63) / 64 * 64;
-  const int64_t w0 = wave * per_wave, w1 = (w0 + per_wave < n) ? w0 + per_wave : n;
-  int cnt = 0;
-  for (int64_t base = w0; base < w1; base += 64) {
-    const int64_t i = base + lane;
-    const bool valid = i < w1;
-    const bool d = valid && dones[i] != 0;
-    if (valid) {
-      cur_r[i] += rewards[i];
-      cur_l[i] += 1;
+// Episode bookkeeping of one env step.  Block b owns envs [b*1024, (b+1)*1024): it counts the finished episodes of the
+// whole step and of the envs before its own (the done flags are one byte per env, so every block can afford to read
+// them all), ranks its own finished episodes in env order with ballots, and places them in the rings at
+// (head + kept - 1 - rank_from_end) mod window exactly like appends to a deque(maxlen=window).  head / num_episodes are
+// only read here; episode_commit_kernel advances them afterwards.
+__device__ __forceinline__ int nonzero_bytes(unsigned w) {
+  unsigned t = w | (w >> 4);
+  t |= t >> 2;
+  t |= t >> 1;
+  return __popc(t & 0x01010101u);
+}
+
+// number of non-zero bytes in dones[0, n) and in dones[0, before): block-wide, returned to every thread
+__device__ __forceinline__ void count_done(const uint8_t* __restrict__ dones, int64_t n, int64_t before, int64_t* total_out, int64_t* before_out) {
+  __shared__ int red[2][4];
+  int tot = 0, bef = 0;
+  if ((reinterpret_cast<uintptr_t>(dones) & 3) == 0) {
+    const unsigned* w = reinterpret_cast<const unsigned*>(dones);
+    const int64_t nw = n >> 2;
+    for (int64_t i = threadIdx.x; i < nw; i += 256) {
+      const int c = nonzero_bytes(w[i]);
+      tot += c;
+      if (4 * i + 4 <= before) bef += c;
+      else if (4 * i < before)
+        for (int k = 0; k < (int)(before - 4 * i); ++k) bef += dones[4 * i + k] != 0;
     }
-    cnt += __popcll(__ballot(d));
+    for (int64_t i = 4 * nw + threadIdx.x; i < n; i += 256) {
+      tot += dones[i] != 0;
+      bef += (i < before) && dones[i] != 0;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      tot += dones[i] != 0;
+      bef += (i < before) && dones[i] != 0;
+    }
   }
-  if (lane == 0) wave_cnt[wave] = cnt;
+  for (int o = 32; o > 0; o >>= 1) {
+    tot += __shfl_xor(tot, o);
+    bef += __shfl_xor(bef, o);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = tot; red[1][wave] = bef; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int64_t run = 0;
-    for (int w = 0; w < 16; ++w) { wave_base[w] = run; run += wave_cnt[w]; }
-    wave_base[16] = run;
+  *total_out = (int64_t)red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  *before_out = (int64_t)red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+__global__ __launch_bounds__(256) void episode_update_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ dones, int64_t n,
+                                                             float* __restrict__ cur_r, int64_t* __restrict__ cur_l, double* __restrict__ ring_r,
+                                                             double* __restrict__ ring_l, int window, const int64_t* __restrict__ head) {
+  constexpr int U = 4;                         // envs per thread: index u*256 + tid of the block's 1024
+  __shared__ int cnt[U][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t start = (int64_t)blockIdx.x * (256 * U);
+  int64_t total, before;
+  count_done(dones, n, start, &total, &before);
+  float val[U];
+  int64_t len[U];
+  bool d[U];
+  unsigned long long m[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = start + u * 256 + threadIdx.x;
+    const bool valid = i < n;
+    d[u] = valid && dones[i] != 0;
+    val[u] = valid ? cur_r[i] + rewards[i] : 0.f;
+    len[u] = valid ? cur_l[i] + 1 : 0;
+    m[u] = __ballot(d[u]);
+    if (lane == 0) cnt[u][wave] = __popcll(m[u]);
   }
   __syncthreads();
-  const int64_t total = wave_base[16], L = window, h0 = head[0];
+  const int64_t L = window, h0 = head[0];
   const int64_t kept = total < L ? total : L;
-  int64_t run = wave_base[wave];
-  for (int64_t base = w0; base < w1; base += 64) {
-    const int64_t i = base + lane;
-    const bool d = i < w1 && dones[i] != 0;
-    const unsigned long long m = __ballot(d);
-    if (d) {
-      const int64_t k = run + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = start + u * 256 + threadIdx.x;
+    if (i >= n) continue;
+    if (d[u]) {
+      int64_t k = before + __popcll(m[u] & ((1ull << lane) - 1ull));
+      for (int q = 0; q < u * 4 + wave; ++q) k += cnt[q >> 2][q & 3];   // finished episodes of the block before this wave's slice
       const int64_t rank_from_end = total - 1 - k;
       if (rank_from_end < L) {
         const int64_t pos = (h0 + kept - 1 - rank_from_end) % L;
-        ring_r[pos] = (double)cur_r[i];
-        ring_l[pos] = (double)cur_l[i];
+        ring_r[pos] = (double)val[u];
+        ring_l[pos] = (double)len[u];
       }
       cur_r[i] = 0.f;
       cur_l[i] = 0;
+    } else {
+      cur_r[i] = val[u];
+      cur_l[i] = len[u];
     }
-    run += __popcll(m);
   }
-  __syncthreads();   // every thread has read head[0]
+}
+
+__global__ __launch_bounds__(256) void episode_commit_kernel(const uint8_t* __restrict__ dones, int64_t n, int window, int64_t* __restrict__ head,
+                                                             int64_t* __restrict__ num_episodes) {
+  int64_t total, before;
+  count_done(dones, n, 0, &total, &before);
   if (threadIdx.x == 0) {
-    head[0] = (h0 + kept) % L;
+    const int64_t L = window;
+    head[0] = (head[0] + (total < L ? total : L)) % L;
     num_episodes[0] += total;
   }
 }
@@ -1097,8 +1145,9 @@ extern "C" int mrl_episode_update(const float* rewards, const uint8_t* dones, in
                                   double* ring_rewards, double* ring_lengths, int32_t window, int64_t* head, int64_t* num_episodes, void* stream) {
   if (!rewards || !dones || !cur_rewards || !cur_lengths || !ring_rewards || !ring_lengths || !head || !num_episodes) MRL_FAIL(MRL_EINVAL, "NULL pointer");
   if (num_envs < 1 || window < 1) MRL_FAIL(MRL_EINVAL, "num_envs %lld, window %d", (long long)num_envs, window);
-  hipLaunchKernelGGL(episode_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, dones, num_envs, cur_rewards, cur_lengths,
-                     ring_rewards, ring_lengths, window, head, num_episodes);
+  hipLaunchKernelGGL(episode_update_kernel, dim3((unsigned)cdiv(num_envs, 1024)), dim3(256), 0, (hipStream_t)stream, rewards, dones, num_envs,
+                     cur_rewards, cur_lengths, ring_rewards, ring_lengths, window, (const int64_t*)head);
+  hipLaunchKernelGGL(episode_commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dones, num_envs, window, head, num_episodes);
   MRL_CHECK_LAUNCH("mrl_episode_update");
   return MRL_OK;
 }
