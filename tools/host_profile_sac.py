@@ -1,3 +1,5 @@
+"""cProfile of the host side of ten SAC epochs at the benchmark configuration of tools/sac_bench.py.
+Run on the GPU box: python tools/host_profile_sac.py"""
 import cProfile, pstats, sys, os, io
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
