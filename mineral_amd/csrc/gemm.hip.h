@@ -794,12 +794,28 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
       const bool jv = j < A;
       float cs0 = 0.f, cs1 = 0.f;                            // column sums of the seeds (bias gradients)
       float m_al = 0.f, m_ent = 0.f, m_bl = 0.f, m_kl = 0.f, m_clip = 0.f;
+      // every per-row input of the 8 iterations is requested up front: one memory round trip instead of eight
+      float in_a[8], in_mu[8], in_sg[8], in_nl[8], in_adv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = wrow0 + it * 4 + g;
+        const int rowc = row < p.M ? row : 0;
+        if constexpr (EPI == EPI_HEADS_TRAIN) {
+          in_a[it] = jv ? hp.actions[(int64_t)rowc * A + j] : 0.f;
+          in_mu[it] = jv ? hp.mu[(int64_t)rowc * A + j] : 0.f;
+          in_sg[it] = jv ? hp.sigma[(int64_t)rowc * A + j] : 1.f;
+          in_nl[it] = hp.old_neglogp[rowc];
+          in_adv[it] = hp.adv[rowc];
+        } else {
+          in_a[it] = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
+          in_mu[it] = in_sg[it] = in_nl[it] = in_adv[it] = 0.f;
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 4 + g;
         const int row = wrow0 + lr;
         const bool rv = row < p.M;
-        const int rowc = rv ? row : 0;
         const float o = T[lr * TS + j];
         const float ls = T[lr * TS + ((A + j) & 31)];
         float mu, sg = 0.f, sigma;
@@ -820,7 +836,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
         if (EPI == EPI_HEADS_ACT && hp.dist_type == DIST_SQUASHED) {
           // rsample + log_prob of the tanh-squashed normal (mineral/nets/distributions.py:10-52, sac.py:118-136):
           // u = mu + sigma*eps, a = tanh(u), log p = sum_j [ log N(u_j) - 2*(log 2 - u_j - softplus(-2 u_j)) ]
-          const float eps = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
+          const float eps = in_a[it];
           const float u = mu + sigma * eps;
           const float a = ftanh(u);
           const float x2 = -2.0f * u;
@@ -836,7 +852,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           if (rv && j == 0) hp.neglogp_out[row] = lp;   // the log-probability itself
         } else if constexpr (EPI == EPI_HEADS_ACT) {
           // mineral/agents/ppo/models.py:115-117 with sample = mu + sigma * noise
-          const float eps = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
+          const float eps = in_a[it];
           const float a = mu + sigma * eps;
           const float d = a - mu;
           float nl = jv ? (d * d) * (0.5f * rsig * rsig) + logsig + MRL_LOG_SQRT_2PI : 0.f;
@@ -851,9 +867,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           if (rv && j == 0) hp.neglogp_out[row] = nl;
         } else {
           // mineral/agents/ppo/models.py:93-107 and mineral/agents/ppo/ppo.py:277-303
-          const float a = jv ? hp.actions[(int64_t)rowc * A + j] : 0.f;
-          const float omu = jv ? hp.mu[(int64_t)rowc * A + j] : 0.f;
-          const float osg = jv ? hp.sigma[(int64_t)rowc * A + j] : 1.f;
+          const float a = in_a[it], omu = in_mu[it], osg = in_sg[it];
           const float d = a - mu;
           const float rvar = rsig * rsig;
           float nl = jv ? (d * d) * (0.5f * rvar) + logsig + MRL_LOG_SQRT_2PI : 0.f;
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
           ent = group_sum16(ent);
           bl = group_sum16(bl);
           kl = group_sum16(kl);
-          const float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
+          const float oldnl = in_nl[it], adv = in_adv[it];
           const float ratio = fexp(oldnl - nl);                  // ppo.py:455
           const float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
           const float rc = fminf(fmaxf(ratio, lo_r), hi_r);
