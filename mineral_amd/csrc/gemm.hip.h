@@ -95,7 +95,7 @@ struct GemmP {
 #ifdef MRL_KTRACE
 // Instrumented diagnostic build (tools/ktrace_run.py): cycle-counter stamps of the four waves of one block.
 constexpr int KTRACE_SLOTS = 1024;
-__device__ unsigned long long g_ktrace[4][KTRACE_SLOTS];
+__device__ unsigned long long g_ktrace[8][KTRACE_SLOTS];   // one row per wave of the traced block (up to 8)
 constexpr int KTRACE_BLOCKS = 8192;
 __device__ unsigned long long g_kblock[KTRACE_BLOCKS][2];   // 100 MHz clock at entry / exit of every block
 #ifdef MRL_KTRACE_ABLATE   // switches inside the main loop change its code; a build of its own keeps the stamps honest
@@ -198,12 +198,13 @@ struct GemmCfg {
   static constexpr int CB = (LB == LAY_K) ? BK : BN;
   static constexpr int SA = CA + 4;                    // padded LDS row strides (floats)
   static constexpr int SB = CB + 4;
-  static constexpr int A_F4 = (RA * CA / 4 + 255) / 256;
-  static constexpr int B_F4 = (RB * CB / 4 + 255) / 256;
+  static constexpr int NT = 64 * WGM * WGN;             // threads per block: one wave per 32-row x (BN / WGN)-column slice
+  static constexpr int A_F4 = (RA * CA / 4 + NT - 1) / NT;
+  static constexpr int B_F4 = (RB * CB / 4 + NT - 1) / NT;
   static constexpr int LDS_TILES = RA * SA + RB * SB;
   static constexpr int LDS_EPI = 2 * BM * WGN + 3 * BN * WGM + 64;   // cross-wave reduction scratch
   static constexpr int LDS_FLOATS = LDS_TILES > LDS_EPI ? LDS_TILES : LDS_EPI;
-  static_assert(WGM * WGN == 4, "256 threads = 4 waves");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 waves (256 threads) or 8 waves (512 threads) per block");
   static_assert(BM % (WGM * 32) == 0 && BN % (WGN * 32) == 0, "wave tiles are multiples of 32x32");
   static_assert(BK % 8 == 0, "k sub-step is 8");
 };
@@ -215,14 +216,16 @@ struct GemmCfg {
 constexpr int gemm_min_waves(int bm, int bn, int epi) { return (epi == EPI_SLAB && bm * bn / 256 <= 64) ? 3 : 2; }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF>
-__global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
   constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
   constexpr bool PRO_ON_A = (PRO != PRO_NONE) && (EPI != EPI_SLAB);
   constexpr bool PRO_ON_B = (PRO != PRO_NONE) && (EPI == EPI_SLAB);
   static_assert(!PRO_ON_A || LA == LAY_K, "forward prologue expects a k-contiguous A");
   static_assert(!PRO_ON_B || LB == LAY_R, "wgrad prologue expects a row-reduction B");
-  static_assert(256 % (C::CA / 4) == 0 && 256 % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
+  constexpr int NT = C::NT;
+  static_assert(NT % (C::CA / 4) == 0 && NT % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
+  static_assert(NT == 256 || EPI == EPI_LNFWD, "8-wave blocks are built for the forward kernels");
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
   constexpr int LDS_ALL = (NBUF * C::LDS_TILES > C::LDS_EPI) ? NBUF * C::LDS_TILES : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
@@ -270,10 +273,10 @@ __global__ __launch_bounds__(256, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // staging: thread `tid` owns column chunk cA / cB (4 floats) of rows rA0 + i*RSTEP of each tile
-  constexpr int A_RSTEP = 256 / (C::CA / 4), B_RSTEP = 256 / (C::CB / 4);
+  constexpr int A_RSTEP = NT / (C::CA / 4), B_RSTEP = NT / (C::CB / 4);
   const int cA = (tid % (C::CA / 4)) * 4, rA0 = tid / (C::CA / 4);
   const int cB = (tid % (C::CB / 4)) * 4, rB0 = tid / (C::CB / 4);
-  constexpr bool A_FULL = (C::RA * C::CA / 4) % 256 == 0, B_FULL = (C::RB * C::CB / 4) % 256 == 0;
+  constexpr bool A_FULL = (C::RA * C::CA / 4) % NT == 0, B_FULL = (C::RB * C::CB / 4) % NT == 0;
   f32x4 ra[C::A_F4], rb[C::B_F4];
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};   // prologue vectors of this thread's column chunk
   if constexpr (PRO_ON_B) {   // wgrad: the feature index n0 + cB does not change along the reduction

@@ -270,7 +270,7 @@ extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flo
 #ifdef MRL_KTRACE
 // instrumented diagnostic build only: copy the cycle stamps of the traced block to host memory
 extern "C" int mrl_debug_ktrace(unsigned long long* dst) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * 4 * KTRACE_SLOTS) == hipSuccess ? 0 : -3;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * 8 * KTRACE_SLOTS) == hipSuccess ? 0 : -3;
 }
 extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_kblock), sizeof(unsigned long long) * 2 * KTRACE_BLOCKS) == hipSuccess ? 0 : -3;
@@ -310,9 +310,9 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
     pt.ktrace = (want && strcmp(want, nm) == 0 && (!want_m || atoi(want_m) == p.M)) ? 1 + (want_z ? atoi(want_z) : 0) : 0;
     pt.ablate = (pt.ktrace && abl) ? atoi(abl) : 0;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), dyn_lds, s, pt);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(64 * WGM * WGN), dyn_lds, s, pt);
 #else
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(256), dyn_lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(64 * WGM * WGN), dyn_lds, s, p);
 #endif
   if (timed) {
     (void)hipEventRecord(e1, s);
@@ -326,13 +326,16 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
 // full-row tiles, selected by the output width; batches of at most MRL_SMALL_M rows take 32-row tiles so that a
 // 2048-row minibatch still spreads over 64 blocks per tower instead of 16
 constexpr int MRL_SMALL_M = 8192;
+// waves per 32-row forward tile of the wide layers on small batches: 8 waves halve the staging and MFMA work of each wave
+// in a regime where a block's serial reduction loop, not the chip's throughput, sets the time
+constexpr int MRL_SMALL_WGN = 8;
 #define MRL_DISPATCH_ROWTILE(N, LA, LB, BKBIG, EPI, PRO, p, towers, s)                                                     \
   do {                                                                                                                    \
     if (p.M <= MRL_SMALL_M) {                                                                                             \
       const dim3 g_((unsigned)cdiv(p.M, 32), 1, towers);                                                                  \
       switch (N) {                                                                                                        \
-        case 512: launch_gemm<32, 512, 16, 1, 4, LA, LB, EPI, PRO, 1>(p, g_, s); break;                                   \
-        case 256: launch_gemm<32, 256, 32, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                      \
+        case 512: launch_gemm<32, 512, 16, 1, MRL_SMALL_WGN, LA, LB, EPI, PRO, 1>(p, g_, s); break;                       \
+        case 256: launch_gemm<32, 256, 32, 1, MRL_SMALL_WGN, LA, LB, EPI, PRO>(p, g_, s); break;                          \
         case 128: launch_gemm<32, 128, BKBIG, 1, 4, LA, LB, EPI, PRO>(p, g_, s); break;                                   \
         case 64: launch_gemm<128, 64, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \
         default: launch_gemm<128, 32, BKBIG, 4, 1, LA, LB, EPI, PRO>(p, dim3((unsigned)cdiv(p.M, 128), 1, towers), s); break;   \

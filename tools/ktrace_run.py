@@ -52,10 +52,10 @@ def main():
                                   _hip.ptr(grads), _hip.ptr(metrics), _hip.ptr(ws), ws.numel(), None), 'mrl_ppo_grad')
     torch.cuda.synchronize()
     slots = 1024
-    host = (C.c_ulonglong * (4 * slots))()
+    host = (C.c_ulonglong * (8 * slots))()
     L.mrl_debug_ktrace.restype = C.c_int
     assert L.mrl_debug_ktrace(host) == 0
-    t = np.frombuffer(host, dtype=np.uint64).reshape(4, slots).astype(np.int64)
+    t = np.frombuffer(host, dtype=np.uint64).reshape(8, slots).astype(np.int64)[:4]   # the first four waves
     nz = int((t[0, :1000] != 0).sum())
     nsteps = (nz - 1) // 2
     e = t[:, 1000:1003]
