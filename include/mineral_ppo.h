@@ -36,10 +36,14 @@ extern "C" {
 #define MRL_DIST_DREAMERV3_NORMAL 1
 #define MRL_NMETRIC 12
 
-/* ActorCritic description: two towers of [Linear -> LayerNorm -> SiLU] x n_layers, heads mu/sigma (actor) and
- * value (critic).  mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.
- * Limits of this build: units multiples of 32 and <= 512, obs_dim multiple of 4, act_dim <= 16,
- * norm_type LayerNorm, act_type SiLU, fixed_sigma False. */
+#define MRL_TOWER_LAYERNORM_SILU 0   /* [Linear -> LayerNorm -> SiLU] per layer (DFlexAntPPO.yaml, AllegroHandPPO.yaml) */
+#define MRL_TOWER_ELU 1              /* [Linear -> ELU] per layer, no normalisation (CartpolePPO.yaml) */
+
+/* ActorCritic description: two towers of n_layers hidden layers, heads mu/sigma (actor) and value (critic).
+ * mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.
+ * tower_kind: one of MRL_TOWER_*.  fixed_sigma != 0: the log-std is a state-independent parameter of act_dim entries
+ * (models.py:66-67,151) stored right after the mu bias; otherwise it is a second head beside mu.
+ * Limits of this build: units in {32,64,128,256,512}, obs_dim multiple of 4, act_dim <= 16. */
 typedef struct mrl_net {
   int32_t obs_dim;
   int32_t act_dim;
@@ -48,6 +52,8 @@ typedef struct mrl_net {
   int32_t dist_type;
   float minstd, maxstd;
   float ln_eps;
+  int32_t tower_kind;
+  int32_t fixed_sigma;
 } mrl_net;
 
 /* RunningMeanStd state, mineral/common/normalizers.py:19-42 (fp64 buffers as built at ppo.py:30). */

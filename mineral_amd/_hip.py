@@ -22,7 +22,8 @@ class HipLibraryError(RuntimeError):
 
 class Net(C.Structure):
     _fields_ = [('obs_dim', C.c_int32), ('act_dim', C.c_int32), ('n_layers', C.c_int32), ('units', C.c_int32 * MAX_LAYERS),
-                ('dist_type', C.c_int32), ('minstd', C.c_float), ('maxstd', C.c_float), ('ln_eps', C.c_float)]
+                ('dist_type', C.c_int32), ('minstd', C.c_float), ('maxstd', C.c_float), ('ln_eps', C.c_float),
+                ('tower_kind', C.c_int32), ('fixed_sigma', C.c_int32)]
 
 
 class Rms(C.Structure):
@@ -164,7 +165,10 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=1e-5):
+TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1}   # (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
+
+
+def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=1e-5, tower_kind=0, fixed_sigma=False):
     if len(units) > MAX_LAYERS:
         raise ValueError(f'at most {MAX_LAYERS} hidden layers are supported, got {len(units)}')
     if dist_type not in DIST_TYPES:
@@ -174,4 +178,5 @@ def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=
     for i, u in enumerate(units):
         n.units[i] = int(u)
     n.dist_type, n.minstd, n.maxstd, n.ln_eps = DIST_TYPES[dist_type], minstd, maxstd, ln_eps
+    n.tower_kind, n.fixed_sigma = int(tower_kind), int(bool(fixed_sigma))
     return n

@@ -26,12 +26,9 @@ class ActorCritic:
             unsupported.append('separate_value_mlp=False')
         if critic_mlp_kwargs is not None:
             unsupported.append('critic_mlp_kwargs')
-        if fixed_sigma:
-            unsupported.append('fixed_sigma=True')
-        if mlp_kwargs.get('norm_type', None) != 'LayerNorm':
-            unsupported.append(f"norm_type={mlp_kwargs.get('norm_type', None)}")
-        if mlp_kwargs.get('act_type', 'ReLU') != 'SiLU':
-            unsupported.append(f"act_type={mlp_kwargs.get('act_type', 'ReLU')}")
+        kind = (mlp_kwargs.get('norm_type', None), mlp_kwargs.get('act_type', 'ReLU'))
+        if kind not in _hip.TOWER_KINDS:
+            unsupported.append(f'norm_type={kind[0]} with act_type={kind[1]} (built: LayerNorm+SiLU, no norm+ELU)')
         if mlp_kwargs.get('dropout', None) is not None or mlp_kwargs.get('plain_last', False) or mlp_kwargs.get('out_dim', None):
             unsupported.append('dropout / plain_last / out_dim')
         if dist.get('dist_type', 'normal') not in _hip.DIST_TYPES:
@@ -41,17 +38,18 @@ class ActorCritic:
         if weight_init != 'orthogonal':
             unsupported.append(f'weight_init={weight_init}')
         if unsupported:
-            raise NotImplementedError('the MI355X PPO kernels cover LayerNorm+SiLU towers with a state-dependent sigma; '
-                                      'unsupported here: ' + ', '.join(unsupported))
+            raise NotImplementedError('unsupported by the MI355X PPO kernels: ' + ', '.join(unsupported))
         self.obs_space, self.action_dim = obs_space, int(action_dim)
         self.obs_dim = int(obs_space['obs'][0])
         self.units = [int(u) for u in mlp_kwargs.get('units', [512, 256, 128])]
         self.ln_eps = float(mlp_kwargs.get('norm_kwargs', {}).get('eps', 1e-5))
         self.dist_type = dist.get('dist_type', 'normal')
         self.minstd, self.maxstd = float(dist.get('minstd', 1.0)), float(dist.get('maxstd', 1.0))
-        self.fixed_sigma, self.separate_value_mlp = False, True
+        self.fixed_sigma, self.separate_value_mlp = bool(fixed_sigma), True
+        self.norm_type, self.act_type = kind
         self.device = torch.device(device)
-        self.net = _hip.make_net(self.obs_dim, self.action_dim, self.units, self.dist_type, self.minstd, self.maxstd, self.ln_eps)
+        self.net = _hip.make_net(self.obs_dim, self.action_dim, self.units, self.dist_type, self.minstd, self.maxstd, self.ln_eps,
+                                 tower_kind=_hip.TOWER_KINDS[kind], fixed_sigma=self.fixed_sigma)
         L = _hip.lib()
         count = L.mrl_param_count(self.net)
         if count < 0:
@@ -74,25 +72,34 @@ class ActorCritic:
         """Views of `flat` under the reference's parameter names, in the order of its model.parameters()."""
         offs = self._offsets()
         A, U = self.action_dim, self.units[-1]
+        has_norm = self.norm_type is not None
+        stride = 3 if has_norm else 2           # modules per layer in the reference's nn.Sequential (mlp.py:50-77)
         v = OrderedDict()
         k = 0
         for tower in ('actor_mlp', 'value_mlp'):
             in_f = self.obs_dim
             for i, u in enumerate(self.units):
-                b = 3 * i
+                b = stride * i
                 v[f'{tower}.mlp.{b}.weight'] = flat[offs[k]: offs[k] + u * in_f].view(u, in_f)
                 v[f'{tower}.mlp.{b}.bias'] = flat[offs[k + 1]: offs[k + 1] + u]
-                v[f'{tower}.mlp.{b + 1}.weight'] = flat[offs[k + 2]: offs[k + 2] + u]
-                v[f'{tower}.mlp.{b + 1}.bias'] = flat[offs[k + 3]: offs[k + 3] + u]
-                k += 4
+                k += 2
+                if has_norm:
+                    v[f'{tower}.mlp.{b + 1}.weight'] = flat[offs[k]: offs[k] + u]
+                    v[f'{tower}.mlp.{b + 1}.bias'] = flat[offs[k + 1]: offs[k + 1] + u]
+                    k += 2
                 in_f = u
         wh, bh, wv, bv = offs[k: k + 4]
         v['value.weight'] = flat[wv: wv + U].view(1, U)
         v['value.bias'] = flat[bv: bv + 1]
         v['mu.weight'] = flat[wh: wh + A * U].view(A, U)
         v['mu.bias'] = flat[bh: bh + A]
-        v['sigma.weight'] = flat[wh + A * U: wh + 2 * A * U].view(A, U)
-        v['sigma.bias'] = flat[bh + A: bh + 2 * A]
+        if self.fixed_sigma:
+            # a direct nn.Parameter of the module (models.py:66-67): first in the reference's parameter order
+            v['sigma'] = flat[bh + A: bh + 2 * A]
+            v.move_to_end('sigma', last=False)
+        else:
+            v['sigma.weight'] = flat[wh + A * U: wh + 2 * A * U].view(A, U)
+            v['sigma.bias'] = flat[bh + A: bh + 2 * A]
         return v
 
     def views_of(self, flat):
@@ -133,7 +140,7 @@ class ActorCritic:
                     v.copy_(w)
                 elif name.endswith('.weight'):   # LayerNorm gain
                     v.fill_(1.0)
-                else:
+                else:                            # biases, and the fixed log-std (models.py:87-88)
                     v.zero_()
 
     def train(self, mode=True):
@@ -147,5 +154,6 @@ class ActorCritic:
         return self
 
     def __repr__(self):
-        return (f'ActorCritic[HIP gfx950](obs={self.obs_dim}, act={self.action_dim}, units={self.units}, LayerNorm+SiLU, '
-                f'dist={self.dist_type}, params={self.param_count})')
+        tower = 'LayerNorm+SiLU' if self.norm_type else 'ELU'
+        return (f'ActorCritic[HIP gfx950](obs={self.obs_dim}, act={self.action_dim}, units={self.units}, {tower}, '
+                f'dist={self.dist_type}{", fixed sigma" if self.fixed_sigma else ""}, params={self.param_count})')

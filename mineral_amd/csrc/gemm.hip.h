@@ -21,8 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { LAY_K = 0, LAY_R = 1 };           // LAY_K: reduction index contiguous; LAY_R: reduction index = row
-enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2 };
-enum { EPI_LNFWD = 0, EPI_LNBWD = 1, EPI_SLAB = 2, EPI_HEADS_TRAIN = 3, EPI_HEADS_ACT = 4 };
+enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2, PRO_ELU = 3 };   // PRO_ELU: plain towers (no normalisation layer), operand = ELU(stored pre-activation)
+enum { EPI_LNFWD = 0, EPI_LNBWD = 1, EPI_SLAB = 2, EPI_HEADS_TRAIN = 3, EPI_HEADS_ACT = 4, EPI_BIASFWD = 5, EPI_ACTBWD = 6 };
 enum { DIST_NORMAL = 0, DIST_DREAMERV3 = 1, DIST_SQUASHED = 2 };   // DIST_SQUASHED: rollout-style sampling only (SAC)
 
 #define MRL_LOG_SQRT_2PI 0.91893853320467274178f
@@ -48,6 +48,7 @@ struct HeadsP {
   float* act_clamped;        // [M][A] clamp(action,-1,1) or null
   float* neglogp_out;        // [M]
   float* value_out;          // [M]
+  const float* fixed_logstd; // [A] state-independent log-std parameter (models.py:66-67,151) or null: log-std from the head
   const double* vrms_mean;   // value_rms state (fp64) or null when normalize_value is off
   const double* vrms_var;
   float vrms_eps;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   static_assert(!PRO_ON_B || LB == LAY_R, "wgrad prologue expects a row-reduction B");
   constexpr int NT = C::NT;
   static_assert(NT % (C::CA / 4) == 0 && NT % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
-  static_assert(NT == 256 || EPI == EPI_LNFWD, "8-wave blocks are built for the forward kernels");
+  static_assert(NT == 256 || EPI == EPI_LNFWD || EPI == EPI_BIASFWD, "8-wave blocks are built for the forward kernels");
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
   constexpr int LDS_ALL = (NBUF * C::LDS_TILES > C::LDS_EPI) ? NBUF * C::LDS_TILES : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   constexpr bool A_FULL = (C::RA * C::CA / 4) % NT == 0, B_FULL = (C::RB * C::CB / 4) % NT == 0;
   f32x4 ra[C::A_F4], rb[C::B_F4];
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};   // prologue vectors of this thread's column chunk
-  if constexpr (PRO_ON_B) {   // wgrad: the feature index n0 + cB does not change along the reduction
+  constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU;   // prologues with per-feature vectors
+  if constexpr (PRO_ON_B && PRO_VEC) {   // wgrad: the feature index n0 + cB does not change along the reduction
     const int gc = min(n0 + cB, last_chunk(Nv));
     pv0 = *reinterpret_cast<const f32x4*>(pro0 + gc);
     pv1 = *reinterpret_cast<const f32x4*>(pro1 + gc);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   }
   const int kstepA = (LA == LAY_K) ? 4 : (int)(p.lda * 4), kstepB = (LB == LAY_K) ? 4 : (int)(p.ldb * 4);   // bytes per reduction index
   rsrc_t rsP0, rsP1;
-  if constexpr (PRO_ON_A) {   // forward prologue vectors follow the reduction offset of the A tile
+  if constexpr (PRO_ON_A && PRO_VEC) {   // forward prologue vectors follow the reduction offset of the A tile
     const int bytes = (kfull - kbeg) * 4;
     rsP0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pro0 + kbeg), 0, bytes, 0x00020000);
     rsP1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pro1 + kbeg), 0, bytes, 0x00020000);
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     }
   };
   auto load_pro = [&](int k0) {
-    if constexpr (PRO_ON_A) {
+    if constexpr (PRO_ON_A && PRO_VEC) {
       pv0 = load16(rsP0, cA * 4, (k0 - kbeg) * 4);
       pv1 = load16(rsP1, cA * 4, (k0 - kbeg) * 4);
     }
@@ -364,6 +366,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     if constexpr (PRO == PRO_NORM) {           // mineral/common/normalizers.py:65-68
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf((v[e] - pv0[e]) / pv1[e], p.clamp_lo), p.clamp_hi);
+    } else if constexpr (PRO == PRO_ELU) {     // F.elu of the stored pre-activation (alpha = 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : __builtin_amdgcn_exp2f(1.44269504088896340736f * v[e]) - 1.0f;
     } else {                                   // LayerNorm affine + SiLU of the stored normalised activation
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     for (int im = 0; im < TM; ++im)
 #pragma unroll
       for (int in = 0; in < TN; ++in)
-        if constexpr (EPI == EPI_LNFWD)   // transposed product: a lane holds one batch row and 16 features per 32x32 tile
+        if constexpr (EPI == EPI_LNFWD || EPI == EPI_BIASFWD)   // transposed product: a lane holds one batch row and 16 features per 32x32 tile
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[in][j], af[im][j], acc[im][in], 0, 0, 0);
         else
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[im][j], bf[in][j], acc[im][in], 0, 0, 0);
@@ -756,6 +761,59 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       for (int w = 0; w < WGM; ++w) sum += cred[w * 3 * BN + i];
       cp[i] = sum;
     }
+  } else if constexpr (EPI == EPI_BIASFWD) {
+    // plain towers (mineral/nets/mlp.py:50-77 with norm_type None): the layer output z = x W^T + b is stored as it is and
+    // the activation is applied by whoever reads it.  Same orientation as EPI_LNFWD: 16-byte stores, one batch row per lane.
+    const float* bias = p.bias[tw];
+    float* outp = p.out[tw] + (int64_t)m0 * BN;
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+      const int row = wm * TM * 32 + im * 32 + l32;
+      float* orow = outp + (int64_t)row * BN + wn * TN * 32 + 4 * h;
+#pragma unroll
+      for (int in = 0; in < TN; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + n0 + wn * TN * 32 + in * 32 + 8 * g + 4 * h);
+          const f32x4 o4 = {acc[im][in][g * 4] + b4[0], acc[im][in][g * 4 + 1] + b4[1], acc[im][in][g * 4 + 2] + b4[2], acc[im][in][g * 4 + 3] + b4[3]};
+          *reinterpret_cast<f32x4*>(orow + in * 32 + 8 * g) = o4;
+        }
+    }
+  } else if constexpr (EPI == EPI_ACTBWD) {
+    // plain towers: acc = d loss / d h with h = elu(z); dz = dh * elu'(z), elu'(z) = 1 for z > 0 and exp(z) otherwise.
+    // Column sums of dz (the bias gradient) go to slot 2 of the column partials, as in EPI_LNBWD.
+    // no row guards: rows >= M carry dh == 0 (their A rows were zero-filled) and the workspace is padded to whole tiles
+    float* cred = lds;                         // [WGM][BN]
+    const rsrc_t z_rs = tile_rsrc(p.xhat[tw] + (int64_t)m0 * BN, BM * BN * 4);
+    const rsrc_t out_rs = tile_rsrc(p.out[tw] + (int64_t)m0 * BN, BM * BN * 4);
+    const int lane_boff = (((wm * TM * 32 + 4 * h) * BN) + wn * TN * 32 + l32) * 4;
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      float cz = 0.f;
+#pragma unroll
+      for (int im = 0; im < TM; ++im) {
+        float zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = buf_load(z_rs, lane_boff, ((im * 32 + (r & 3) + 8 * (r >> 2)) * BN + in * 32) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = zv[r] > 0.f ? 1.0f : __builtin_amdgcn_exp2f(1.44269504088896340736f * zv[r]);
+          const float dz = acc[im][in][r] * d;
+          buf_store(dz, out_rs, lane_boff, ((im * 32 + (r & 3) + 8 * (r >> 2)) * BN + in * 32) * 4);
+          cz += dz;
+        }
+      }
+      cz += __shfl_xor(cz, 32);
+      if (h == 0) cred[wm * BN + colof(in)] = cz;
+    }
+    __syncthreads();
+    float* cp = p.colpart[tw] + (int64_t)blockIdx.x * 3 * BN + 2 * BN;
+    for (int i = tid; i < BN; i += 256) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) sum += cred[w * BN + i];
+      cp[i] = sum;
+    }
   } else if constexpr (EPI == EPI_HEADS_TRAIN || EPI == EPI_HEADS_ACT) {
     static_assert(TN == 1 && WGN == 1 && TM == 1, "heads use a 32-wide tile, one 32x32 block per wave");
     const HeadsP& hp = p.h;
@@ -820,7 +878,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
         const int row = wrow0 + lr;
         const bool rv = row < p.M;
         const float o = T[lr * TS + j];
-        const float ls = T[lr * TS + ((A + j) & 31)];
+        const float ls = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : T[lr * TS + ((A + j) & 31)];
         float mu, sg = 0.f, sigma;
         if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
           mu = ftanh(o);

@@ -44,10 +44,12 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct ParamLayout {
   int64_t W[2][MRL_MAX_LAYERS], b[2][MRL_MAX_LAYERS], g[2][MRL_MAX_LAYERS], be[2][MRL_MAX_LAYERS];
-  int64_t Wh[2], bh[2];   // heads: [head_rows][U] / [head_rows] per tower
+  int64_t Wh[2], bh[2];   // heads: [head_rows][U] / [head_bias_n] per tower
   int64_t total;
   int in_dim[MRL_MAX_LAYERS];
   int n_towers, head_rows[2];
+  int head_bias_n[2];     // entries of the head's bias tensor: head_rows, plus the act_dim log-std entries when sigma is fixed
+  bool has_norm;          // LayerNorm gain / bias per layer (absent in the plain ELU towers)
 };
 
 static int check_net(const mrl_net* net) {
@@ -60,14 +62,18 @@ static int check_net(const mrl_net* net) {
     if (!(u == 32 || u == 64 || u == 128 || u == 256 || u == 512)) MRL_FAIL(MRL_EINVAL, "units[%d]=%d must be 32/64/128/256/512", l, u);
   }
   if (net->dist_type != MRL_DIST_NORMAL && net->dist_type != MRL_DIST_DREAMERV3_NORMAL) MRL_FAIL(MRL_EINVAL, "dist_type %d unsupported", net->dist_type);
+  if (net->tower_kind != MRL_TOWER_LAYERNORM_SILU && net->tower_kind != MRL_TOWER_ELU) MRL_FAIL(MRL_EINVAL, "tower_kind %d unsupported", net->tower_kind);
+  if (net->fixed_sigma != 0 && net->fixed_sigma != 1) MRL_FAIL(MRL_EINVAL, "fixed_sigma %d not in {0, 1}", net->fixed_sigma);
   return MRL_OK;
 }
 
-// Flat layout of `n_towers` MLP towers ([W, b, ln_gamma, ln_beta] per layer) followed by one head per tower
-// ([head_rows][U] weights, [head_rows] bias); every tensor starts at a multiple of 4 floats.
-static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int n_towers, const int* head_rows, ParamLayout* L) {
+// Flat layout of `n_towers` MLP towers ([W, b, ln_gamma, ln_beta] per layer, or [W, b] without a normalisation layer)
+// followed by one head per tower ([head_rows][U] weights, [head_bias_n] bias); every tensor starts at a multiple of 4 floats.
+static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int n_towers, const int* head_rows, ParamLayout* L,
+                            bool has_norm = true, const int* head_bias_n = nullptr) {
   int64_t o = 0;
   memset(L, 0, sizeof(*L));
+  L->has_norm = has_norm;
   for (int tw = 0; tw < n_towers; ++tw) {
     int in = in_dim0;
     for (int l = 0; l < n_layers; ++l) {
@@ -75,25 +81,31 @@ static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int
       L->in_dim[l] = in;
       L->W[tw][l] = o; o = align4(o + (int64_t)u * in);
       L->b[tw][l] = o; o = align4(o + u);
-      L->g[tw][l] = o; o = align4(o + u);
-      L->be[tw][l] = o; o = align4(o + u);
+      if (has_norm) {
+        L->g[tw][l] = o; o = align4(o + u);
+        L->be[tw][l] = o; o = align4(o + u);
+      }
       in = u;
     }
   }
   const int U = units[n_layers - 1];
   for (int tw = 0; tw < n_towers; ++tw) {
     L->head_rows[tw] = head_rows[tw];
+    L->head_bias_n[tw] = head_bias_n ? head_bias_n[tw] : head_rows[tw];
     L->Wh[tw] = o; o = align4(o + (int64_t)head_rows[tw] * U);
-    L->bh[tw] = o; o = align4(o + head_rows[tw]);
+    L->bh[tw] = o; o = align4(o + L->head_bias_n[tw]);
   }
   L->n_towers = n_towers;
   L->total = o;
 }
 
-// ActorCritic: actor tower with the [mu; sigma] head, critic tower with the value head
+// ActorCritic: actor tower with the [mu; sigma] head (or the mu head with [mu bias; log-std] when sigma is fixed), critic
+// tower with the value head
 static void param_layout(const mrl_net* net, ParamLayout* L) {
-  const int hr[2] = {2 * net->act_dim, 1};
-  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L);
+  const int A = net->act_dim;
+  const int hr[2] = {net->fixed_sigma ? A : 2 * A, 1};
+  const int hb[2] = {2 * A, 1};
+  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L, net->tower_kind == MRL_TOWER_LAYERNORM_SILU, hb);
 }
 
 extern "C" int64_t mrl_param_count(const mrl_net* net) {
@@ -111,7 +123,8 @@ extern "C" int mrl_param_offsets(const mrl_net* net, int64_t* offs, int32_t* n) 
   int k = 0;
   for (int tw = 0; tw < 2; ++tw)
     for (int l = 0; l < net->n_layers; ++l) {
-      offs[k++] = L.W[tw][l]; offs[k++] = L.b[tw][l]; offs[k++] = L.g[tw][l]; offs[k++] = L.be[tw][l];
+      offs[k++] = L.W[tw][l]; offs[k++] = L.b[tw][l];
+      if (L.has_norm) { offs[k++] = L.g[tw][l]; offs[k++] = L.be[tw][l]; }
     }
   offs[k++] = L.Wh[0]; offs[k++] = L.bh[0]; offs[k++] = L.Wh[1]; offs[k++] = L.bh[1];
   *n = k;
@@ -171,7 +184,8 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
       w->rstd[tw][l] = o; o = align64(o + rows_pad);
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
-      w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
+      if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
+      else w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
@@ -367,6 +381,7 @@ static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hip
 static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers, hipStream_t s) {
   if (pro == PRO_NORM) launch_wgrad_pro<PRO_NORM>(p, w, towers, s);
   else if (pro == PRO_LNSILU) launch_wgrad_pro<PRO_LNSILU>(p, w, towers, s);
+  else if (pro == PRO_ELU) launch_wgrad_pro<PRO_ELU>(p, w, towers, s);
   else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
@@ -382,9 +397,9 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       int tw = tw0 + t;
       p.A[t] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
       p.B[t] = params + L.W[tw][l];
-      p.pro0[t] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
-      p.pro1[t] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
-      p.out[t] = ws + W.xhat[tw][l];
+      p.pro0[t] = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
+      p.pro1[t] = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
+      p.out[t] = ws + W.xhat[tw][l];   // plain towers keep the pre-activation z in the same slot
       p.rstd[t] = ws + W.rstd[tw][l];
       p.bias[t] = params + L.b[tw][l];
     }
@@ -393,7 +408,11 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.Nt[0] = p.Nt[1] = u; p.Kt[0] = p.Kt[1] = in;
     p.clamp_lo = lo; p.clamp_hi = hi;
     p.ln_eps = net->ln_eps;
-    if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    if (net->tower_kind == MRL_TOWER_ELU) {
+      if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_ELU, p, towers, s);
+      else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NORM, p, towers, s);
+      else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NONE, p, towers, s);
+    } else if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
     else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
   }
@@ -1067,12 +1086,13 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     int tw = tw0 + k;
     p.A[k] = ws + W.xhat[tw][last];
     p.B[k] = params + L.Wh[tw];
-    p.pro0[k] = params + L.g[tw][last];
-    p.pro1[k] = params + L.be[tw][last];
+    p.pro0[k] = L.has_norm ? params + L.g[tw][last] : nullptr;
+    p.pro1[k] = L.has_norm ? params + L.be[tw][last] : nullptr;
     p.bias[k] = params + L.bh[tw];
-    p.Nt[k] = (tw == 0) ? 2 * A : 1;
+    p.Nt[k] = L.head_rows[tw];
     p.Kt[k] = U;
   }
+  if (net->fixed_sigma) p.h.fixed_logstd = params + L.bh[0] + A;
   p.tw0 = tw0;
   p.lda = U; p.ldb = U;
   p.M = (int)N; p.N = 32; p.K = U;
@@ -1087,7 +1107,8 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     p.h.vrms_mean = value_rms->mean; p.h.vrms_var = value_rms->var; p.h.vrms_eps = value_rms->eps;
     p.clamp_lo = value_rms->clamp_lo; p.clamp_hi = value_rms->clamp_hi;
   }
-  launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   MRL_CHECK_LAUNCH("mrl_policy_act");
   return MRL_OK;
 }
@@ -1243,14 +1264,22 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       p.out[k] = ws + W.dz[tw][l];
       p.xhat[k] = ws + W.xhat[tw][l];
       p.rstd[k] = ws + W.rstd[tw][l];
-      p.gamma[k] = params + L.g[tw][l];
-      p.beta[k] = params + L.be[tw][l];
+      p.gamma[k] = L.has_norm ? params + L.g[tw][l] : nullptr;
+      p.beta[k] = L.has_norm ? params + L.be[tw][l] : nullptr;
       p.colpart[k] = ws + W.colpart[tw][l];
     }
     const int kdim = (l == last) ? 32 : net->units[l + 1];
     p.lda = kdim; p.ldb = u; p.ldo = u;
     p.M = (int)mb; p.N = u; p.K = kdim;
-    if (ln_bwd_streamed(u)) {
+    if (net->tower_kind == MRL_TOWER_ELU) {
+      // plain towers: dgrad fused with the ELU derivative of the layer below, full-row tiles (bias-gradient partials per row block)
+      const dim3 grid((unsigned)cdiv(p.M, fwd_bm(u)), 1, towers);
+      if (u == 512) launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+      else if (u == 256) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+      else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+      else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+      else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+    } else if (ln_bwd_streamed(u)) {
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
       p.ksplit = kdim; p.n_tiles = u / 128; p.group_mode = 0;
       if (mb <= MRL_SMALL_M) {   // 32-row tiles: four times the blocks for a batch that would leave most CUs idle
@@ -1314,8 +1343,8 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       const int tw = tw0 + k;
       p.A[k] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
       p.B[k] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
-      p.pro0[k] = (l == 0) ? obs_mean : params + L.g[tw][l - 1];
-      p.pro1[k] = (l == 0) ? obs_std : params + L.be[tw][l - 1];
+      p.pro0[k] = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
+      p.pro1[k] = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
       p.out[k] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
       p.Nt[k] = gn; p.Kt[k] = (int)mb;
     }
@@ -1324,7 +1353,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
     p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
     p.n_groups = wp.nsplit; p.group_mode = 1;
-    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : PRO_LNSILU, towers, s);
+    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : (L.has_norm ? PRO_LNSILU : PRO_ELU), towers, s);
   }
 }
 
@@ -1350,14 +1379,16 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
       add(ws + W.slab[tw][l], L.W[tw][l], (int64_t)u * L.in_dim[l], (int64_t)u * L.in_dim[l], W.wp[l].nsplit);
       const float* cp = ws + W.colpart[tw][l];
       add(cp + 2 * u, L.b[tw][l], u, 3 * u, W.rowblocks[l]);
-      add(cp, L.g[tw][l], u, 3 * u, W.rowblocks[l]);
-      add(cp + u, L.be[tw][l], u, 3 * u, W.rowblocks[l]);
+      if (L.has_norm) {
+        add(cp, L.g[tw][l], u, 3 * u, W.rowblocks[l]);
+        add(cp + u, L.be[tw][l], u, 3 * u, W.rowblocks[l]);
+      }
       if ((int64_t)u * L.in_dim[l] > maxcount) maxcount = (int64_t)u * L.in_dim[l];
     }
     const int hn = L.head_rows[tw];
     add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
     // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
-    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(hn), 64, hblocks);
+    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(L.head_bias_n[tw]), 64, hblocks);
   }
   int gx = (int)cdiv(maxcount, 64);
   if (gx > 2048) gx = 2048;
@@ -1394,13 +1425,14 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     for (int tw = 0; tw < 2; ++tw) {
       p.A[tw] = ws + W.xhat[tw][last];
       p.B[tw] = params + L.Wh[tw];
-      p.pro0[tw] = params + L.g[tw][last];
-      p.pro1[tw] = params + L.be[tw][last];
+      p.pro0[tw] = L.has_norm ? params + L.g[tw][last] : nullptr;
+      p.pro1[tw] = L.has_norm ? params + L.be[tw][last] : nullptr;
       p.bias[tw] = params + L.bh[tw];
-      p.Nt[tw] = (tw == 0) ? 2 * A : 1;
+      p.Nt[tw] = L.head_rows[tw];
       p.Kt[tw] = U;
       p.h.seeds[tw] = ws + W.seeds[tw];
     }
+    if (net->fixed_sigma) p.h.fixed_logstd = params + L.bh[0] + A;
     p.lda = U; p.ldb = U;
     p.M = (int)mb; p.N = 32; p.K = U;
     fill_heads_common(net, &p.h);
@@ -1416,7 +1448,8 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.inv_mb = 1.0f / (float)mb;
     p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
-    launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, 2), s);
+    if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, 2), s);
+    else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, 2), s);
   }
   hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
                      hp->entropy_coef, hp->bounds_loss_coef, metrics_out);

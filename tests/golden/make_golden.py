@@ -154,6 +154,9 @@ NETS = {
                      dist=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0)),
     'small_normal': dict(obs=5, act=3, units=[16, 8], norm=None, act_type='ELU', fixed_sigma=True,
                          dist=dict(dist_type='normal')),
+    # the network of cfgs/agent/CartpolePPO.yaml (no normalisation layer, ELU, state-independent log-std) at widths the
+    # device kernels take
+    'cartpole': dict(obs=4, act=1, units=[32, 32], norm=None, act_type='ELU', fixed_sigma=True, dist=dict(dist_type='normal')),
 }
 
 
@@ -330,6 +333,11 @@ def g6_g8():
               dump_first_step=True, params_every_epoch=False)
 
 
+def g8_cartpole():
+    run_agent('g8_train_cartpole_adam', NETS['cartpole'], N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim_type='Adam',
+              dump_first_step=True, params_every_epoch=False)
+
+
 # ---- G9 / G10: seeds and schedulers -------------------------------------------------------------------
 def g9_g10():
     seeds = {}
@@ -349,9 +357,13 @@ def g9_g10():
 
 
 if __name__ == '__main__':
+    if os.environ.get('GOLDEN_ONLY') == 'g8_cartpole':      # add one fixture without rewriting the others
+        g8_cartpole()
+        sys.exit(0)
     g1_g2()
     g3()
     g4()
     g5()
     g6_g8()
+    g8_cartpole()
     g9_g10()

@@ -48,22 +48,33 @@ NETS = {
     'mid': dict(obs=64, act=12, units=[128, 64, 32]),
     'full': dict(obs=64, act=12, units=[512, 256, 128]),
     'wide2': dict(obs=20, act=3, units=[256, 32]),
+    # plain towers (no normalisation layer, ELU) as in cfgs/agent/CartpolePPO.yaml, with the state-independent log-std
+    'cartpole': dict(obs=4, act=1, units=[32, 32], norm=None, actf='ELU', fixed=True),
+    'elu_wide': dict(obs=20, act=3, units=[256, 64], norm=None, actf='ELU', fixed=True),
+    'elu_head': dict(obs=64, act=12, units=[512, 128], norm=None, actf='ELU', fixed=False),
+    'ln_fixed': dict(obs=64, act=12, units=[128, 64], fixed=True),
 }
 
 
 def oracle_cfg(spec, dist='dreamerv3_normal'):
-    return O.NetConfig(spec['obs'], spec['act'], spec['units'], 'LayerNorm', 'SiLU', False, dist, 0.1, 1.0)
+    return O.NetConfig(spec['obs'], spec['act'], spec['units'], spec.get('norm', 'LayerNorm'), spec.get('actf', 'SiLU'), spec.get('fixed', False),
+                       dist, 0.1, 1.0)
 
 
 def oracle_params(spec, seed):
-    shapes = synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], True, True, False)
-    return synth.make_params(shapes, seed)
+    shapes = synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], spec.get('norm', 'LayerNorm') is not None, True,
+                                       spec.get('fixed', False))
+    p = synth.make_params(shapes, seed)
+    if 'sigma' in p:
+        p['sigma'] = p['sigma'] * 0.3 - 0.4      # a log-std away from its zero initial value
+    return p
 
 
 def make_model(spec, params, dist='dreamerv3_normal'):
     from mineral_amd.agents.ppo.models import ActorCritic
-    m = ActorCritic({'obs': (spec['obs'],)}, spec['act'], mlp_kwargs=dict(units=spec['units'], norm_type='LayerNorm', act_type='SiLU'),
-                    fixed_sigma=False, actor_dist_kwargs=dict(dist_type=dist, minstd=0.1, maxstd=1.0), device=DEV)
+    m = ActorCritic({'obs': (spec['obs'],)}, spec['act'],
+                    mlp_kwargs=dict(units=spec['units'], norm_type=spec.get('norm', 'LayerNorm'), act_type=spec.get('actf', 'SiLU')),
+                    fixed_sigma=spec.get('fixed', False), actor_dist_kwargs=dict(dist_type=dist, minstd=0.1, maxstd=1.0), device=DEV)
     m.load_state_dict(params)
     return m
 
@@ -148,7 +159,8 @@ def test_batch_moments_groups(hip):
 
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('net,N,dist', [('mid', 64, 'dreamerv3_normal'), ('full', 16, 'dreamerv3_normal'), ('full', 300, 'normal'),
-                                       ('wide2', 129, 'dreamerv3_normal')])
+                                       ('wide2', 129, 'dreamerv3_normal'), ('cartpole', 100, 'normal'), ('elu_wide', 300, 'normal'),
+                                       ('elu_head', 77, 'dreamerv3_normal'), ('ln_fixed', 64, 'normal')])
 def test_policy_act(hip, golden, net, N, dist):
     from mineral_amd.common.normalizers import RunningMeanStd
     spec = NETS[net]
@@ -237,6 +249,11 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('full', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
     ('wide2', 37, 8, 148, 'dreamerv3_normal', 0, 'bound'),
     ('full', 32, 32, 1024, 'dreamerv3_normal', 0, 'bound'),
+    ('cartpole', 64, 8, 128, 'normal', 0, 'bound'),
+    ('cartpole', 37, 8, 296, 'normal', 1, 'reg'),
+    ('elu_wide', 50, 8, 200, 'normal', 0, 'bound'),
+    ('elu_head', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
+    ('ln_fixed', 64, 8, 256, 'normal', 0, 'bound'),
 ])
 def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
     spec = NETS[net]
@@ -330,22 +347,27 @@ def _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, logdir):
         agent=dict(algo='PPO', print_every=-1, ckpt_every=-1, tracker_len=100, metrics_kwargs={},
                    network=dict(normalize_input=True, actor_critic='ActorCritic',
                                 actor_critic_kwargs=dict(separate_value_mlp=True,
-                                                         mlp_kwargs=dict(units=spec['units'], norm_type='LayerNorm', act_type='SiLU'),
-                                                         fixed_sigma=False,
-                                                         actor_dist_kwargs=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0))),
+                                                         mlp_kwargs=dict(units=spec['units'], norm_type=spec.get('norm', 'LayerNorm'),
+                                                                         act_type=spec.get('actf', 'SiLU')),
+                                                         fixed_sigma=spec.get('fixed', False),
+                                                         actor_dist_kwargs=(dict(dist_type='normal') if spec.get('fixed', False) else
+                                                                            dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0)))),
                    ppo=ppo)))
 
 
-def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path):
-    """PPO.train() of the product on the deterministic env against what the REFERENCE produced (fixture g8 mid)."""
+@pytest.mark.parametrize('fixture,net,optim', [('g8_train_mid_dv3_adamw', 'mid', 'AdamW'), ('g8_train_cartpole_adam', 'cartpole', 'Adam')])
+def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path, fixture, net, optim):
+    """PPO.train() of the product on the deterministic env against what the REFERENCE produced: the LayerNorm+SiLU net
+    with a sigma head (fixture g8 mid) and the network of CartpolePPO.yaml (no norm, ELU, state-independent log-std)."""
     from mineral_amd.agents import PPO
-    g = golden('g8_train_mid_dv3_adamw')
-    spec = NETS['mid']
+    g = golden(fixture)
+    spec = NETS[net]
     N, T, mb, mini_epochs, epochs = 64, 8, 128, 2, 2
-    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, str(tmp_path))
     env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
     agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
-    agent.model.load_state_dict(oracle_params(spec, 5))
+    agent.model.load_state_dict(synth.make_params(synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'],
+                                                                            spec.get('norm', 'LayerNorm') is not None, True, spec.get('fixed', False)), 5))
     agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
     agent.save = lambda *a, **k: None
     agent._checkpoint_save = lambda *a, **k: None
@@ -547,3 +569,26 @@ def test_launcher_cli_trains_and_writes_the_reference_artifacts(tmp_path):
     assert {'epoch', 'mini_epoch', 'agent_steps', 'model', 'optim', 'obs_rms', 'value_rms'} <= set(ckpt)
     assert ckpt['agent_steps'] == 24576 and ckpt['epoch'] == 2
     assert 'actor_mlp.mlp.0.weight' in ckpt['model'] and ckpt['obs_rms']['obs.running_count'].dtype == torch.float64
+
+
+@pytest.mark.gpu
+def test_launcher_cli_runs_the_cartpole_network(tmp_path):
+    """`agent=CartpolePPO` (no normalisation layer, ELU, state-independent log-std; mineral/cfgs/agent/CartpolePPO.yaml) through
+    the launcher: the checkpoint carries the reference's parameter names for that network."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logdir = str(tmp_path / 'run')
+    cmd = [sys.executable, '-m', 'mineral.scripts.run', 'task=Synthetic', 'agent=CartpolePPO', 'num_envs=128', 'agent.ppo.minibatch_size=1024',
+           'agent.ppo.max_agent_steps=6144', 'agent.print_every=1', f'logdir={logdir}', 'seed=3']
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert 'Traceback' not in res.stderr and 'Exception:' not in res.stdout, (res.stdout[-1500:], res.stderr[-1500:])
+    ckpt = torch.load(os.path.join(logdir, 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
+    names = list(ckpt['model'])
+    assert names[0] == 'sigma' and ckpt['model']['sigma'].shape == (12,)
+    assert 'actor_mlp.mlp.2.weight' in names and 'actor_mlp.mlp.1.weight' not in names and 'sigma.weight' not in names
+    assert ckpt['model']['actor_mlp.mlp.0.weight'].shape == (32, 64) and ckpt['agent_steps'] == 6144
+    assert all(torch.isfinite(v).all() for v in ckpt['model'].values())
+

@@ -24,6 +24,7 @@ NETS = {
                          dist_type='normal'),
     'mid_dv3': dict(obs=64, act=12, units=[128, 64, 32], norm='LayerNorm', act_type='SiLU', fixed_sigma=False,
                     dist_type='dreamerv3_normal'),
+    'cartpole': dict(obs=4, act=1, units=[32, 32], norm=None, act_type='ELU', fixed_sigma=True, dist_type='normal'),
 }
 
 
@@ -156,6 +157,7 @@ TRAIN_CASES = [
     ('g8_train_small_dv3_adam', 'small_dv3', dict(N=16, T=8, mb=64, mini_epochs=2, epochs=2, optim='Adam')),
     ('g8_train_small_normal_adam', 'small_normal', dict(N=16, T=8, mb=64, mini_epochs=2, epochs=2, optim='Adam')),
     ('g8_train_mid_dv3_adamw', 'mid_dv3', dict(N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim='AdamW')),
+    ('g8_train_cartpole_adam', 'cartpole', dict(N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim='Adam')),
 ]
 
 
@@ -217,8 +219,10 @@ def test_end_to_end_training(golden, fixture, net, c):
             close(np.array(res[k], dtype=np.float32), g[f'e{e}_{k.replace("/", "_")}'], rtol=2e-4, atol=2e-6)
         close(data['mu'], g[f'e{e}_data_mu'], **tol)
         close(data['sigma'], g[f'e{e}_data_sigma'], **tol)
-        close(obs_rms['running_mean'], g[f'e{e}_obs_rms_mean'], rtol=1e-9, atol=1e-12)
-        close(obs_rms['running_var'], g[f'e{e}_obs_rms_var'], rtol=1e-9, atol=1e-12)
+        # the batch moments are fp32 torch reductions whose association depends on the layout of the minibatch view: one
+        # fp32 ulp of a batch mean is 6e-8 relative
+        close(obs_rms['running_mean'], g[f'e{e}_obs_rms_mean'], rtol=1e-7, atol=1e-9)
+        close(obs_rms['running_var'], g[f'e{e}_obs_rms_var'], rtol=1e-7, atol=1e-9)
         exact(obs_rms['running_count'], g[f'e{e}_obs_rms_count'])
         close(value_rms['running_mean'], g[f'e{e}_value_rms_mean'], rtol=1e-6, atol=1e-9)
         close(value_rms['running_var'], g[f'e{e}_value_rms_var'], rtol=1e-6, atol=1e-9)
