@@ -85,8 +85,17 @@ def test_parameter_views_match_reference_names_and_count():
     m.load_state_dict(params)
     flat2 = m.flat.clone()
     assert torch.equal(m.views_of(flat2)['sigma.bias'], params['sigma.bias'])
+    # the network of CartpolePPO.yaml: no normalisation layer (Linear at every second index), ELU, `sigma` a direct parameter
+    c = ActorCritic({'obs': (4,)}, 1, mlp_kwargs=dict(units=[32, 32], norm_type=None, act_type='ELU'), fixed_sigma=True,
+                    actor_dist_kwargs=dict(dist_type='normal'), device='cpu')
+    cshapes = synth.actor_critic_shapes(4, 1, [32, 32], False, True, True)
+    assert [n for n, _ in c.named_parameters()] == [n for n, _ in cshapes]
+    assert all(tuple(v.shape) == s for (_, v), (_, s) in zip(c.named_parameters(), cshapes))
+    assert float(c.state_dict()['sigma'].abs().sum()) == 0            # models.py:87-88
+    with pytest.raises(NotImplementedError):                           # pairs without kernels
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='ELU'), fixed_sigma=True, device='cpu')
     with pytest.raises(NotImplementedError):
-        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ELU'), fixed_sigma=True, device='cpu')
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ReLU'), fixed_sigma=False, device='cpu')
 
 
 def test_schedulers_match_reference_tables(golden):
