@@ -93,6 +93,7 @@ typedef struct mrl_ppo_hp {
   float bounds_loss_coef;
   int32_t bounds_type;       /* 0 'bound', 1 'reg' (ppo.py:479-489) */
   int32_t clip_value_loss;
+  int32_t use_smooth_clamp;  /* ratio clamp of the actor loss: 0 torch.clamp, 1 smooth_clamp (ppo.py:449-457) */
 } mrl_ppo_hp;
 
 const char* mrl_last_error(void);

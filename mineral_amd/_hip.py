@@ -40,7 +40,7 @@ class Rollout(C.Structure):
 
 class PpoHp(C.Structure):
     _fields_ = [('e_clip', C.c_float), ('critic_coef', C.c_float), ('entropy_coef', C.c_float), ('bounds_loss_coef', C.c_float),
-                ('bounds_type', C.c_int32), ('clip_value_loss', C.c_int32)]
+                ('bounds_type', C.c_int32), ('clip_value_loss', C.c_int32), ('use_smooth_clamp', C.c_int32)]
 
 
 class Transitions(C.Structure):

@@ -81,8 +81,7 @@ class PPO(Agent):
         # --- PPO params (ppo.py:62-83) ---
         c = self.ppo_config
         self.e_clip = c['e_clip']
-        if c['use_smooth_clamp']:
-            raise NotImplementedError('use_smooth_clamp')
+        self.use_smooth_clamp = bool(c['use_smooth_clamp'])
         self.clip_value_loss = c['clip_value_loss']
         self.entropy_coef, self.critic_coef = c['entropy_coef'], c['critic_coef']
         self.bounds_loss_coef, self.bounds_type = c['bounds_loss_coef'], c['bounds_type']
@@ -113,7 +112,7 @@ class PPO(Agent):
                                         self.obs_space, self.action_dim, dev, self.cpu_obs_keys)
         self.reward_shaper = RewardShaper(**c['reward_shaper'])
         self.hp = _hip.PpoHp(self.e_clip, self.critic_coef, self.entropy_coef, self.bounds_loss_coef,
-                             0 if self.bounds_type == 'bound' else 1, int(bool(self.clip_value_loss)))
+                             0 if self.bounds_type == 'bound' else 1, int(bool(self.clip_value_loss)), int(self.use_smooth_clamp))
 
         # --- Scratch: sized once for max(num_envs, minibatch) rows; nothing is allocated inside the loops ---
         L = _hip.lib()

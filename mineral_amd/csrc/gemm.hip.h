@@ -41,7 +41,7 @@ struct HeadsP {
   double* metric_part;       // [gridDim.x][2][MRL_NMETRIC]
   float* headb_part;         // [gridDim.x][2][32] column sums of the seeds (head bias gradients)
   float inv_mb, e_clip, critic_coef, entropy_coef, bounds_coef;
-  int bounds_type, clip_value_loss;
+  int bounds_type, clip_value_loss, smooth_clamp;
   // rollout (EPI_HEADS_ACT)
   const float* noise;        // [M][A] standard normal
   float* act_out;            // actions  -> act_out[row*out_rs + out_off + j]
@@ -956,10 +956,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           const float oldnl = in_nl[it], adv = in_adv[it];
           const float ratio = fexp(oldnl - nl);                  // ppo.py:455
           const float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
-          const float rc = fminf(fmaxf(ratio, lo_r), hi_r);
+          float rc = fminf(fmaxf(ratio, lo_r), hi_r);
+          float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;      // d clamp / d ratio
+          if (hp.smooth_clamp) {                                            // ppo.py:449-450: a sigmoid between the bounds
+            const float sc = frcp(1.0f + fexp((-(ratio - lo_r) * frcp(hi_r - lo_r) + 0.5f) * 4.0f));
+            rc = sc * (hi_r - lo_r) + lo_r;
+            inr = 4.0f * sc * (1.0f - sc);
+          }
           const float x1 = -(adv * ratio), x2 = -(adv * rc);
           const float al = fmaxf(x1, x2);
-          const float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;
           const float dratio = (x1 > x2) ? -adv : (x1 < x2) ? -adv * inr : 0.5f * (-adv) + 0.5f * (-adv * inr);
           const float dnl = hp.inv_mb * dratio * (-ratio);
           const float dmu = dnl * (-d * rvar) + hp.bounds_coef * hp.inv_mb * dbl;

@@ -1448,6 +1448,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.inv_mb = 1.0f / (float)mb;
     p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
+    p.h.smooth_clamp = hp->use_smooth_clamp != 0;
     if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, 2), s);
     else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, 2), s);
   }

@@ -246,6 +246,7 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
 @pytest.mark.parametrize('net,N,T,mb,dist,clipv,btype', [
     ('mid', 64, 8, 128, 'dreamerv3_normal', 0, 'bound'),
     ('mid', 50, 4, 100, 'normal', 1, 'reg'),
+    ('mid', 64, 8, 128, 'dreamerv3_normal', 2, 'bound'),     # clipv 2: smooth_clamp of the ratio (ppo.py:449-457)
     ('full', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
     ('wide2', 37, 8, 148, 'dreamerv3_normal', 0, 'bound'),
     ('full', 32, 32, 1024, 'dreamerv3_normal', 0, 'bound'),
@@ -262,9 +263,10 @@ def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
     model = make_model(spec, params, dist)
     buf = make_buffer(spec, N, T, mb)
     data = _fill_training_buffer(spec, buf, N, T)
+    smooth, clipv = clipv == 2, clipv & 1
     hp = O.PPOHParams(horizon_len=T, minibatch_size=mb, clip_value_loss=bool(clipv), bounds_type=btype, entropy_coef=0.01,
-                      bounds_loss_coef=0.05 if dist == 'normal' else 1e-4)
-    chp = hip.PpoHp(hp.e_clip, hp.critic_coef, hp.entropy_coef, hp.bounds_loss_coef, 0 if btype == 'bound' else 1, clipv)
+                      bounds_loss_coef=0.05 if dist == 'normal' else 1e-4, use_smooth_clamp=smooth)
+    chp = hip.PpoHp(hp.e_clip, hp.critic_coef, hp.entropy_coef, hp.bounds_loss_coef, 0 if btype == 'bound' else 1, clipv, int(smooth))
     L = hip.lib()
     ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
     grads = torch.full((model.param_count,), float('nan'), device=DEV)
@@ -455,7 +457,7 @@ def test_full_size_properties(hip):
     s['actions'].normal_(generator=g).mul_(0.5)
     L = hip.lib()
     ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
-    chp = hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0)
+    chp = hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0, 0)
     mean_f = torch.zeros(64, device=DEV); std_f = torch.ones(64, device=DEV)
     metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
     outs = []

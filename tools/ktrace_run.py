@@ -41,7 +41,7 @@ def main():
     for k in ('advantages', 'returns', 'values'):
         buf._flat[k].copy_(torch.randn(B, device=dev, generator=g))
     L = _hip.lib()
-    chp = _hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0)
+    chp = _hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0, 0)
     ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=dev)
     grads = torch.zeros(model.param_count, device=dev)
     metrics = torch.zeros(_hip.NMETRIC, dtype=torch.float64, device=dev)
