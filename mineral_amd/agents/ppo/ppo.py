@@ -181,7 +181,12 @@ class PPO(Agent):
     def play_steps(self):
         for n in range(self.horizon_len):
             if not self.env_autoresets:
-                raise NotImplementedError('env_autoresets=False')
+                # ppo.py:136-142: envs that do not reset themselves are reset here, one host round trip per step like there
+                done_ids = torch.where(torch.as_tensor(self.dones, device=self.device).reshape(-1) != 0)[0]
+                if done_ids.numel() > 0:
+                    obs_reset = self._convert_obs(self.env.reset_idx(done_ids.tolist()))
+                    for k, v in obs_reset.items():
+                        self.obs[k][done_ids] = v
             actions = self.model_act(self.obs, n)
             obs, r, self.dones, infos = self.env.step(actions)           # ppo.py:150-151
             self.obs = self._convert_obs(obs)

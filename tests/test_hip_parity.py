@@ -594,3 +594,39 @@ def test_launcher_cli_runs_the_cartpole_network(tmp_path):
     assert ckpt['model']['actor_mlp.mlp.0.weight'].shape == (32, 64) and ckpt['agent_steps'] == 6144
     assert all(torch.isfinite(v).all() for v in ckpt['model'].values())
 
+
+@pytest.mark.gpu
+def test_env_autoresets_false_resets_finished_envs_before_the_next_step(hip, tmp_path):
+    """task.env_autoresets=False (ppo.py:136-142): finished envs are reset through env.reset_idx and their fresh observation is
+    what the next policy step sees and stores."""
+    from mineral_amd.agents import PPO
+
+    class ManualResetEnv(synth.GoldenEnv):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.reset_calls = []
+
+        def reset_idx(self, ids):
+            self.reset_calls.append((self.t, list(ids)))
+            return torch.full((len(ids), self.obs_dim), 7.0 + self.t, device=self.device)
+
+    spec = NETS['mid']
+    N, T = 16, 8
+    cfg = _agent_cfg(spec, N, T, N * T, 1, 1, 'Adam', str(tmp_path))
+    cfg.task['env_autoresets'] = False
+    env = ManualResetEnv(N, spec['obs'], spec['act'], device=DEV)       # episode_length 5, staggered counters
+    agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    agent.save = lambda *a, **k: None
+    agent._checkpoint_save = lambda *a, **k: None
+    agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
+    agent.train()
+    obs_buf = cpu(agent.storage.storage_dict['obses']['obs'])            # (N, T, O)
+    dones = cpu(agent.storage.storage_dict['dones'])                     # (T, N) as stored per step
+    assert env.reset_calls, 'some env must have finished within the horizon'
+    for t_env, ids in env.reset_calls:
+        # the reset happens at the top of rollout step t_env (env.t counts completed steps), after the dones of step t_env - 1
+        assert sorted(ids) == torch.nonzero(dones.reshape(T, N)[t_env - 1]).flatten().tolist()
+        assert torch.all(obs_buf[ids, t_env] == 7.0 + t_env)
+        others = [i for i in range(N) if i not in ids]
+        assert not torch.any(obs_buf[others, t_env] == 7.0 + t_env)
+
