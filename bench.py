@@ -173,7 +173,7 @@ def main():
 
     env_steps = args.num_envs * T_HORIZON * world * args.steps
     out = {
-        'metric': 'PPO env-steps/sec, synthetic env (obs=64, act=12), 65536 envs per MI355X',
+        'metric': f'PPO env-steps/sec, synthetic env (obs=64, act=12), {args.num_envs} envs per MI355X',
         'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
