@@ -39,6 +39,14 @@ int64_t mrl_critic_workspace_bytes(const mrl_critic_net* net, int64_t rows);
 int mrl_tdlambda_targets(const float* rew, const float* done_mask, const float* next_values, int64_t num_envs, int32_t horizon, double gamma,
                          double lam, int32_t one_step, float* target_values, void* stream);
 
+/* SHAC.compute_target_values_with_entropy after its entropy transforms (mineral/agents/diffrl/shac.py:900-916): the same
+ * targets with rew + alpha * entropy in place of rew.  entropy: [horizon][num_envs], already offset / scaled by the target
+ * entropy where the config asks for it (shac.py:894-898 are element-wise and stay with the caller); alpha: the entropy
+ * coefficient or the current temperature. */
+int mrl_tdlambda_targets_entropy(const float* rew, const float* done_mask, const float* next_values, const float* entropy, double alpha,
+                                 int64_t num_envs, int32_t horizon, double gamma, double lam, int32_t one_step, float* target_values,
+                                 void* stream);
+
 /* EnsembleCritic.forward(return_type='all') (models.py:236-243): values [n_critics][rows].  obs is normalised with
  * (obs_mean, obs_std, clamp) when given. */
 int mrl_critic_values(const mrl_critic_net* net, const float* params, const float* obs, int64_t rows, const float* obs_mean, const float* obs_std,

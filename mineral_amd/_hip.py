@@ -117,6 +117,7 @@ _SIGNATURES = {
     'mrl_critic_param_offsets': (C.c_int, [C.POINTER(CriticNet), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'mrl_critic_workspace_bytes': (C.c_int64, [C.POINTER(CriticNet), C.c_int64]),
     'mrl_tdlambda_targets': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, _P, _P]),
+    'mrl_tdlambda_targets_entropy': (C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, _P, _P]),
     'mrl_critic_values': (C.c_int, [C.POINTER(CriticNet), _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, C.c_int64, _P]),
     'mrl_critic_mse_grad': (C.c_int, [C.POINTER(CriticNet), _P, _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P]),
     'mrl_lerp_params': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P]),

@@ -146,6 +146,29 @@ def compute_target_values(rew_buf, done_mask, next_values, gamma, lam=0.95, crit
     return out
 
 
+def compute_target_values_with_entropy(rew_buf, done_mask, next_values, entropy, alpha, gamma, lam=0.95, critic_method='td-lambda',
+                                       offset_by_target_entropy=False, scale_by_target_entropy=False, target_entropy=None, out=None):
+    """shac.py:893-916.  `entropy` is the distribution entropy or -logprobs, (horizon, num_envs); `alpha` the entropy
+    coefficient or the current temperature as a Python float."""
+    if critic_method not in ('one-step', 'td-lambda'):
+        raise NotImplementedError(critic_method)
+    T, N = rew_buf.shape
+    if offset_by_target_entropy:
+        entropy = (entropy + abs(target_entropy)) * 0.5
+    if scale_by_target_entropy:
+        entropy = entropy * (1.0 / abs(target_entropy))
+    entropy = entropy.contiguous()
+    for t in (rew_buf, done_mask, next_values, entropy):
+        if t.shape != (T, N) or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError('compute_target_values_with_entropy: buffers must be contiguous fp32 (horizon, num_envs) device tensors')
+    if out is None:
+        out = torch.empty_like(rew_buf)
+    _hip.check(_hip.lib().mrl_tdlambda_targets_entropy(_hip.ptr(rew_buf), _hip.ptr(done_mask), _hip.ptr(next_values), _hip.ptr(entropy), float(alpha), N, T,
+                                                       float(gamma), float(lam), 1 if critic_method == 'one-step' else 0, _hip.ptr(out), _stream()),
+               'mrl_tdlambda_targets_entropy')
+    return out
+
+
 class CriticDataset:
     """utils.py:39-69: (T, B, ...) buffers flattened time-major into contiguous batches, the last one short unless drop_last."""
 

@@ -34,6 +34,29 @@ def target_values(rew, done_mask, next_values, gamma, lam, method='td-lambda'):
     return out
 
 
+def target_values_with_entropy(rew, done_mask, next_values, entropy, alpha, gamma, lam, method='td-lambda', offset_by_target_entropy=False,
+                               scale_by_target_entropy=False, target_entropy=None):
+    """shac.py:893-916: the entropy bonus alpha * entropy joins the reward before the scan; `entropy` is -logprobs or the
+    distribution entropy, (T, N)."""
+    if offset_by_target_entropy:
+        entropy = (entropy + abs(target_entropy)) * 0.5
+    if scale_by_target_entropy:
+        entropy = entropy * (1.0 / abs(target_entropy))
+    if method == 'one-step':
+        return (rew + alpha * entropy) + gamma * next_values
+    T, N = rew.shape
+    Ai, Bi, lm = torch.zeros(N), torch.zeros(N), torch.ones(N)
+    out = torch.zeros(T, N)
+    for i in reversed(range(T)):
+        lm = lm * lam * (1.0 - done_mask[i]) + done_mask[i]
+        r = rew[i] + alpha * entropy[i]
+        adjusted = (1.0 - lm) / (1.0 - lam) * r
+        Ai = (1.0 - done_mask[i]) * (lam * gamma * Ai + gamma * next_values[i] + adjusted)
+        Bi = gamma * (next_values[i] * done_mask[i] + Bi * (1.0 - done_mask[i])) + r
+        out[i] = (1.0 - lam) * Ai + lm * Bi
+    return out
+
+
 def dataset_batches(obs, targets, batch_size):
     """CriticDataset without shuffle (utils.py:39-69): (T, N, ...) flattened time-major, contiguous slices, last one short."""
     o, t = obs.reshape(-1, obs.shape[-1]), targets.reshape(-1)

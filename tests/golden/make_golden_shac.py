@@ -61,6 +61,26 @@ for case, (N, T, O, units, n_critics, n_batches, iters, optim_type, lr, max_norm
     for k, v in target.state_dict().items():
         out[f'{case}_target.{k}'] = v.numpy().copy()
 
+# entropy-augmented targets (shac.py:893-916), every combination of the two entropy transforms, both methods
+ent_out = {}
+for case, (N, T, *_rest) in synth.SHAC_CASES.items():
+    obs, rew, done, nv = synth.shac_inputs(case)
+    logp = synth.gaussianish((T, N), 23) * 1.5 - 2.0
+    for method in ('td-lambda', 'one-step'):
+        for offset in (False, True):
+            for scale in (False, True):
+                ns = types.SimpleNamespace(critic_method=method, rew_buf=rew, gamma=0.99, lam=0.95, next_values=nv, done_mask=done, num_envs=N,
+                                           device='cpu', horizon_len=T, target_values=torch.zeros(T, N), use_distr_ent=False, logprobs=logp,
+                                           offset_by_target_entropy=offset, scale_by_target_entropy=scale, target_entropy=-3.0,
+                                           with_autoent=False, entropy_coef=0.05)
+                ref_shac.SHAC.compute_target_values_with_entropy(ns)
+                ent_out[f'{case}_{method}_o{int(offset)}s{int(scale)}'] = ns.target_values.numpy().copy()
+ent_path = os.path.join(HERE, 'g14_shac_entropy_targets.npz')
+np.savez_compressed(ent_path, **ent_out)
+print('wrote', ent_path, os.path.getsize(ent_path), 'bytes,', len(ent_out), 'arrays')
+if os.environ.get('GOLDEN_ONLY') == 'g14':
+    sys.exit(0)
+
 path = os.path.join(HERE, 'g13_shac_critic.npz')
 np.savez_compressed(path, **out)
 print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')

@@ -49,6 +49,20 @@ def test_target_values_bit_exact_vs_oracle(N, T, gamma, lam):
         assert torch.equal(got, want), method
 
 
+@pytest.mark.parametrize('case', sorted(synth.SHAC_CASES))
+def test_entropy_target_values_bit_exact_vs_reference(case):
+    from mineral_amd.agents.diffrl import compute_target_values_with_entropy
+    GE = np.load(os.path.join(ROOT, 'tests', 'golden', 'g14_shac_entropy_targets.npz'))
+    N, T = synth.SHAC_CASES[case][:2]
+    obs, rew, done, nv = synth.shac_inputs(case)
+    ent = (-1.0 * (synth.gaussianish((T, N), 23) * 1.5 - 2.0)).to(DEV)
+    for method in ('td-lambda', 'one-step'):
+        for offset in (False, True):
+            for scale in (False, True):
+                got = compute_target_values_with_entropy(rew.to(DEV), done.to(DEV), nv.to(DEV), ent, 0.05, 0.99, 0.95, method, offset, scale, -3.0)
+                assert np.array_equal(got.cpu().numpy(), GE[f'{case}_{method}_o{int(offset)}s{int(scale)}']), (method, offset, scale)
+
+
 def test_target_values_rejects_bad_arguments():
     from mineral_amd.agents.diffrl import compute_target_values
     z = torch.zeros(4, 8, device=DEV)

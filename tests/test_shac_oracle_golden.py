@@ -45,3 +45,18 @@ def test_update_critic_and_soft_update(case):
     S.soft_update(pc, pt, 0.2)
     for k, v in pt.items():
         assert torch.allclose(v, torch.from_numpy(G[f'{case}_target.{k}']), rtol=2e-5, atol=2e-6), k
+
+
+
+@pytest.mark.parametrize('case', sorted(synth.SHAC_CASES))
+def test_entropy_target_values_bit_exact(case):
+    """compute_target_values_with_entropy (shac.py:893-916) for both methods and the four entropy-transform combinations."""
+    GE = np.load(os.path.join(ROOT, 'tests', 'golden', 'g14_shac_entropy_targets.npz'))
+    N, T = synth.SHAC_CASES[case][:2]
+    obs, rew, done, nv = synth.shac_inputs(case)
+    logp = synth.gaussianish((T, N), 23) * 1.5 - 2.0
+    for method in ('td-lambda', 'one-step'):
+        for offset in (False, True):
+            for scale in (False, True):
+                got = S.target_values_with_entropy(rew, done, nv, -1.0 * logp, 0.05, 0.99, 0.95, method, offset, scale, -3.0)
+                assert np.array_equal(got.numpy(), GE[f'{case}_{method}_o{int(offset)}s{int(scale)}']), (method, offset, scale)
