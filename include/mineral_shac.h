@@ -15,15 +15,20 @@
 extern "C" {
 #endif
 
+#define MRL_CRITIC_ACT_SILU 0
+#define MRL_CRITIC_ACT_ELU 1
+
 /* EnsembleCritic / Critic (mineral/agents/diffrl/models.py:149-256): n_critics (1 or 2) towers of
- * [Linear -> LayerNorm -> SiLU] x n_layers on the observation, each ending in a plain Linear to 1.  Widths in
- * {32,64,128,256,512}; obs_dim a multiple of 4. */
+ * [Linear -> LayerNorm -> activation] x n_layers on the observation, each ending in a plain Linear to 1.  act_type: SiLU
+ * (DFlexAntSHAC2.yaml, DFlexAntSAPO.yaml) or ELU (DFlexAntSHAC.yaml).  Widths in {32,64,128,256,512}; obs_dim a multiple
+ * of 4. */
 typedef struct mrl_critic_net {
   int32_t obs_dim;
   int32_t n_critics;
   int32_t n_layers;
   int32_t units[MRL_MAX_LAYERS];
   float ln_eps;
+  int32_t act_type;
 } mrl_critic_net;
 
 /* Flat parameter vector: tower 0, (tower 1,) head 0, (head 1); offsets per tower per layer W, b, ln_gamma, ln_beta, then per

@@ -70,13 +70,19 @@ def make_sac_net(obs_dim, act_dim, actor_units, critic_units, minlogstd=-5.0, ma
 
 class CriticNet(C.Structure):
     """mrl_critic_net (include/mineral_shac.h)."""
-    _fields_ = [('obs_dim', C.c_int32), ('n_critics', C.c_int32), ('n_layers', C.c_int32), ('units', C.c_int32 * MAX_LAYERS), ('ln_eps', C.c_float)]
+    _fields_ = [('obs_dim', C.c_int32), ('n_critics', C.c_int32), ('n_layers', C.c_int32), ('units', C.c_int32 * MAX_LAYERS), ('ln_eps', C.c_float),
+                ('act_type', C.c_int32)]
 
 
-def make_critic_net(obs_dim, n_critics, units, ln_eps=1e-5):
+CRITIC_ACTS = {'SiLU': 0, 'ELU': 1}
+
+
+def make_critic_net(obs_dim, n_critics, units, ln_eps=1e-5, act_type='SiLU'):
     if len(units) > MAX_LAYERS:
         raise NotImplementedError(f'at most {MAX_LAYERS} layers per tower')
-    return CriticNet(obs_dim, n_critics, len(units), (C.c_int32 * MAX_LAYERS)(*units), ln_eps)
+    if act_type not in CRITIC_ACTS:
+        raise NotImplementedError(f'act_type={act_type}')
+    return CriticNet(obs_dim, n_critics, len(units), (C.c_int32 * MAX_LAYERS)(*units), ln_eps, CRITIC_ACTS[act_type])
 
 
 _P = C.c_void_p

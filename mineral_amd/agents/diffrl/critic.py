@@ -21,23 +21,32 @@ class EnsembleCritic(_Flat):
     """models.py:181-256 with with_vmap=False, n_sample=None: n_critics towers on the observation, each ending in a plain
     Linear to 1.  One flat fp32 device vector in the library's layout; `state_dict` uses the reference's names."""
 
+    DEFAULT_MLP_KWARGS = dict(act_type='ELU', norm_type='LayerNorm')   # models.py:154,189
+
     def __init__(self, state_dim, action_dim=None, n_critics=1, n_sample=None, with_vmap=False, mlp_kwargs=None, weight_init='orthogonal', device='cuda'):
+        if n_critics not in (1, 2) or n_sample is not None or with_vmap:
+            raise NotImplementedError('the HIP critic ensemble has n_critics in {1, 2}, n_sample=None, with_vmap=False')
+        self._setup(state_dim, [f'critics.{c}' for c in range(n_critics)], mlp_kwargs, weight_init, device)
+
+    def _setup(self, state_dim, prefixes, mlp_kwargs, weight_init, device):
         _hip.lib()
-        units = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'EnsembleCritic')
-        if n_critics not in (1, 2) or n_sample is not None or with_vmap or weight_init not in ('orthogonal', 'orthogonalg1'):
-            raise NotImplementedError('the HIP critic ensemble has n_critics in {1, 2}, n_sample=None, with_vmap=False, '
-                                      'weight_init in {orthogonal, orthogonalg1}')
+        kw = dict(self.DEFAULT_MLP_KWARGS if mlp_kwargs is None else mlp_kwargs)
+        units = _mlp_kwargs_ok(kw, type(self).__name__, acts=tuple(_hip.CRITIC_ACTS))
+        if weight_init not in ('orthogonal', 'orthogonalg1'):
+            raise NotImplementedError(f'weight_init={weight_init}: the HIP critics cover orthogonal and orthogonalg1')
         if not str(device).startswith('cuda'):
             raise _hip.HipLibraryError(f'the critic runs on an MI355X only (device={device}); no CPU fallback')
-        self.net = _hip.make_critic_net(int(state_dim), int(n_critics), units)
+        self.act_type = kw['act_type']
+        self.net = _hip.make_critic_net(int(state_dim), len(prefixes), units, act_type=self.act_type)
         parts = []
-        for c in range(n_critics):
-            parts += _tower_parts(f'critics.{c}', state_dim, units)
+        for pre in prefixes:
+            parts += _tower_parts(pre, state_dim, units)
         b = 3 * len(units)
-        for c in range(n_critics):
-            parts += [[(f'critics.{c}.mlp.{b}.weight', (1, units[-1]))], [(f'critics.{c}.mlp.{b}.bias', (1,))]]
+        for pre in prefixes:
+            parts += [[(f'{pre}.mlp.{b}.weight', (1, units[-1]))], [(f'{pre}.mlp.{b}.bias', (1,))]]
         super().__init__(self.net, None, parts, device)
-        self.units, self.n_critics, self.state_dim = units, int(n_critics), int(state_dim)
+        self.units, self.n_critics, self.state_dim = units, len(prefixes), int(state_dim)
+        self._prefixes = list(prefixes)
         self.weight_init = weight_init
         self._ws = None
         self.reset_parameters()
@@ -70,8 +79,8 @@ class EnsembleCritic(_Flat):
 
     def _ordered(self):
         keys = []
-        for c in range(self.n_critics):
-            keys += [k for k in self._views if k.startswith(f'critics.{c}.')]
+        for pre in self._prefixes:
+            keys += [k for k in self._views if k.startswith(pre + '.')]
         return collections.OrderedDict((k, self._views[k]) for k in keys)
 
     def workspace(self, rows):
@@ -82,8 +91,7 @@ class EnsembleCritic(_Flat):
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, x, return_type='min'):
-        """models.py:235-256.  x (..., state_dim) fp32 (or {'z': x}); values come back shaped (..., 1) per critic."""
+    def _values(self, x):
         if isinstance(x, dict):
             x = x['z']
         lead = x.shape[:-1]
@@ -93,7 +101,11 @@ class EnsembleCritic(_Flat):
         ws = self.workspace(rows)
         _hip.check(_hip.lib().mrl_critic_values(self.net, _hip.ptr(self.flat), _hip.ptr(flat), rows, None, None, 0.0, 0.0, _hip.ptr(out), _hip.ptr(ws),
                                                 ws.numel(), _stream()), 'mrl_critic_values')
-        Vs = out.view(self.n_critics, *lead, 1)
+        return out.view(self.n_critics, *lead, 1)
+
+    def forward(self, x, return_type='min'):
+        """models.py:235-256.  x (..., state_dim) fp32 (or {'z': x}); values come back shaped (..., 1) per critic."""
+        Vs = self._values(x)
         if return_type == 'all':
             return Vs
         if return_type == 'min':
@@ -106,7 +118,7 @@ class EnsembleCritic(_Flat):
 
     def clone(self):
         """deepcopy for the target critic (shac.py:166)."""
-        other = object.__new__(EnsembleCritic)
+        other = object.__new__(type(self))
         other.__dict__.update(self.__dict__)
         other.flat = self.flat.clone()
         other._views = other.views_of(other.flat)
@@ -114,7 +126,24 @@ class EnsembleCritic(_Flat):
         return other
 
     def __repr__(self):
-        return f'EnsembleCritic[HIP gfx950](n_critics={self.n_critics}, units={self.units}, LayerNorm+SiLU, params={self.param_count})'
+        return f'{type(self).__name__}[HIP gfx950](n_critics={self.n_critics}, units={self.units}, LayerNorm+{self.act_type}, params={self.param_count})'
+
+
+class Critic(EnsembleCritic):
+    """models.py:149-178: one tower under the name `critic_mlp` (the critic of DFlexAntSHAC.yaml, LayerNorm + ELU)."""
+
+    def __init__(self, state_dim, action_dim=None, mlp_kwargs=None, weight_init='orthogonal', device='cuda'):
+        self._setup(state_dim, ['critic_mlp'], mlp_kwargs, weight_init, device)
+
+    def forward(self, x, return_type=None):
+        v = self._values(x)[0]
+        if return_type == 'all':
+            return [v]
+        if return_type == 'min_and_avg':
+            return v, v.clone()
+        return v
+
+    __call__ = forward
 
 
 def soft_update(module, module_target, alpha):

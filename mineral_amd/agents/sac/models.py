@@ -11,16 +11,16 @@ import torch
 from ... import _hip
 
 
-def _mlp_kwargs_ok(kw, what):
+def _mlp_kwargs_ok(kw, what, acts=('SiLU',)):
     bad = []
     if kw.get('norm_type', None) != 'LayerNorm':
         bad.append(f"norm_type={kw.get('norm_type', None)}")
-    if kw.get('act_type', 'ReLU') != 'SiLU':
+    if kw.get('act_type', 'ReLU') not in acts:
         bad.append(f"act_type={kw.get('act_type', 'ReLU')}")
     if kw.get('dropout', None) is not None:
         bad.append('dropout')
     if bad:
-        raise NotImplementedError(f'{what}: the MI355X kernels cover LayerNorm+SiLU towers; unsupported here: ' + ', '.join(bad))
+        raise NotImplementedError(f"{what}: the MI355X kernels cover LayerNorm+{'/'.join(acts)} towers; unsupported here: " + ', '.join(bad))
     return [int(u) for u in kw.get('units', [512, 256, 128])]
 
 

@@ -21,7 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { LAY_K = 0, LAY_R = 1 };           // LAY_K: reduction index contiguous; LAY_R: reduction index = row
-enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2, PRO_ELU = 3 };   // PRO_ELU: plain towers (no normalisation layer), operand = ELU(stored pre-activation)
+// PRO_ELU: plain towers (no normalisation layer), operand = ELU(stored pre-activation); PRO_LNELU: LayerNorm affine, then ELU
+enum { PRO_NONE = 0, PRO_NORM = 1, PRO_LNSILU = 2, PRO_ELU = 3, PRO_LNELU = 4 };
 enum { EPI_LNFWD = 0, EPI_LNBWD = 1, EPI_SLAB = 2, EPI_HEADS_TRAIN = 3, EPI_HEADS_ACT = 4, EPI_BIASFWD = 5, EPI_ACTBWD = 6 };
 enum { DIST_NORMAL = 0, DIST_DREAMERV3 = 1, DIST_SQUASHED = 2 };   // DIST_SQUASHED: rollout-style sampling only (SAC)
 
@@ -65,8 +66,8 @@ struct GemmP {
   int M, N, K;                 // GEMM sizes (M rows, N cols, K reduction); all loads are guarded by these
   int Nt[2], Kt[2];            // per-tower valid N / K (the heads differ: 2*act_dim vs 1); 0 = use N / K
   int tw0;                     // role of blockIdx.z == 0: 0 actor, 1 critic (critic-only launches)
-  const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU: gamma[f]
-  const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU: beta[f]
+  const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU / PRO_LNELU: gamma[f]
+  const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU / PRO_LNELU: beta[f]
   float clamp_lo, clamp_hi;
   // EPI_SLAB launches use a 1-D grid of 8*ceil(groups/8)*group_size blocks.  A group is the set of tiles that read the
   // same operand rows (dgrad: the N tiles of one row block; wgrad: all tiles of one batch split); its blocks are given
@@ -86,6 +87,7 @@ struct GemmP {
   const float* beta[2];        // LNBWD
   float* colpart[2];           // LNBWD: [gridDim.x][3][N]  (dgamma, dbeta, dbias partial column sums)
   float ln_eps;
+  int act_elu;                 // LN backward: the activation after the LayerNorm is ELU (else SiLU)
   HeadsP h;
 #ifdef MRL_KTRACE
   int ktrace;                  // instrumented diagnostic build only: 1 + z = block 8 of tower z records cycle stamps
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   constexpr bool A_FULL = (C::RA * C::CA / 4) % NT == 0, B_FULL = (C::RB * C::CB / 4) % NT == 0;
   f32x4 ra[C::A_F4], rb[C::B_F4];
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};   // prologue vectors of this thread's column chunk
-  constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU;   // prologues with per-feature vectors
+  constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU || PRO == PRO_LNELU;   // prologues with per-feature vectors
   if constexpr (PRO_ON_B && PRO_VEC) {   // wgrad: the feature index n0 + cB does not change along the reduction
     const int gc = min(n0 + cB, last_chunk(Nv));
     pv0 = *reinterpret_cast<const f32x4*>(pro0 + gc);
@@ -369,6 +371,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     } else if constexpr (PRO == PRO_ELU) {     // F.elu of the stored pre-activation (alpha = 1)
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : __builtin_amdgcn_exp2f(1.44269504088896340736f * v[e]) - 1.0f;
+    } else if constexpr (PRO == PRO_LNELU) {   // LayerNorm affine + ELU of the stored normalised activation
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = v[e] * pv0[e] + pv1[e];
+        o[e] = y > 0.f ? y : __builtin_amdgcn_exp2f(1.44269504088896340736f * y) - 1.0f;
+      }
     } else {                                   // LayerNorm affine + SiLU of the stored normalised activation
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -674,8 +682,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
         const int r = hf * 8 + e;
         const float x = xb[b & 1][e];
         const float y = x * gv[in] + bv[in];
-        const float sgm = sigmoid_fast(y);
-        const float dy = ea[im][in][r] * (sgm * (1.0f + y * (1.0f - sgm)));
+        float dact;                            // derivative of the activation at y
+        if (p.act_elu) dact = y > 0.f ? 1.0f : __builtin_amdgcn_exp2f(1.44269504088896340736f * y);
+        else {
+          const float sgm = sigmoid_fast(y);
+          dact = sgm * (1.0f + y * (1.0f - sgm));
+        }
+        const float dy = ea[im][in][r] * dact;
         sg[in] += dy * x;
         sb[in] += dy;
         const float dxh = dy * gv[in];

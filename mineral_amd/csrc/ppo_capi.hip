@@ -99,13 +99,15 @@ static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int
   L->total = o;
 }
 
+constexpr int TOWER_LAYERNORM_ELU = 2;   // LayerNorm + ELU: the critic of DFlexAntSHAC.yaml; reached through the critic entry points only
+
 // ActorCritic: actor tower with the [mu; sigma] head (or the mu head with [mu bias; log-std] when sigma is fixed), critic
 // tower with the value head
 static void param_layout(const mrl_net* net, ParamLayout* L) {
   const int A = net->act_dim;
   const int hr[2] = {net->fixed_sigma ? A : 2 * A, 1};
   const int hb[2] = {2 * A, 1};
-  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L, net->tower_kind == MRL_TOWER_LAYERNORM_SILU, hb);
+  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L, net->tower_kind != MRL_TOWER_ELU, hb);
 }
 
 extern "C" int64_t mrl_param_count(const mrl_net* net) {
@@ -382,6 +384,7 @@ static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers
   if (pro == PRO_NORM) launch_wgrad_pro<PRO_NORM>(p, w, towers, s);
   else if (pro == PRO_LNSILU) launch_wgrad_pro<PRO_LNSILU>(p, w, towers, s);
   else if (pro == PRO_ELU) launch_wgrad_pro<PRO_ELU>(p, w, towers, s);
+  else if (pro == PRO_LNELU) launch_wgrad_pro<PRO_LNELU>(p, w, towers, s);
   else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
@@ -412,7 +415,8 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_ELU, p, towers, s);
       else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NORM, p, towers, s);
       else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NONE, p, towers, s);
-    } else if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    } else if (l > 0 && net->tower_kind == TOWER_LAYERNORM_ELU) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNELU, p, towers, s);
+    else if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
     else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
   }
@@ -816,6 +820,7 @@ struct LnBwdArgs {
   const float* beta[2];
   float* colpart[2];   // [gridDim.x][3][N]
   int M, rows_per_block;
+  int act_elu;         // the activation after the LayerNorm is ELU (else SiLU)
 };
 
 template <int N>
@@ -850,8 +855,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float y = x[c][e] * g[c][e] + b[c][e];
-        const float sg = sigmoid_fast(y);
-        const float dy = d[c][e] * (sg * (1.0f + y * (1.0f - sg)));
+        float dact;
+        if (a.act_elu) dact = y > 0.f ? 1.0f : __builtin_amdgcn_exp2f(1.44269504088896340736f * y);
+        else {
+          const float sg = sigmoid_fast(y);
+          dact = sg * (1.0f + y * (1.0f - sg));
+        }
+        const float dy = d[c][e] * dact;
         cg[c][e] += dy * x[c][e];
         cb[c][e] += dy;
         const float dxh = dy * g[c][e];
@@ -1271,6 +1281,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     const int kdim = (l == last) ? 32 : net->units[l + 1];
     p.lda = kdim; p.ldb = u; p.ldo = u;
     p.M = (int)mb; p.N = u; p.K = kdim;
+    p.act_elu = net->tower_kind == TOWER_LAYERNORM_ELU;
     if (net->tower_kind == MRL_TOWER_ELU) {
       // plain towers: dgrad fused with the ELU derivative of the layer below, full-row tiles (bias-gradient partials per row block)
       const dim3 grid((unsigned)cdiv(p.M, fwd_bm(u)), 1, towers);
@@ -1297,6 +1308,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
         a.gamma[k] = params + L.g[tw][l]; a.beta[k] = params + L.be[tw][l]; a.colpart[k] = ws + W.colpart[tw][l];
       }
       a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
+      a.act_elu = net->tower_kind == TOWER_LAYERNORM_ELU;
       dim3 grid(W.rowblocks[l], towers);
       if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
@@ -1353,7 +1365,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
     p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
     p.n_groups = wp.nsplit; p.group_mode = 1;
-    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : (L.has_norm ? PRO_LNSILU : PRO_ELU), towers, s);
+    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : (L.has_norm ? (net->tower_kind == TOWER_LAYERNORM_ELU ? PRO_LNELU : PRO_LNSILU) : PRO_ELU), towers, s);
   }
 }
 

@@ -5,8 +5,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 by calling the reference's own `SHAC.compute_target_values`, `CriticDataset` and `SHAC.update_critic` here.
 
 Follows mineral/agents/diffrl/shac.py:824-889 (update_critic, compute_critic_loss, compute_target_values),
-mineral/agents/diffrl/utils.py:25-69 (soft_update, grad_norm, CriticDataset) and mineral/agents/diffrl/models.py:181-256
-(EnsembleCritic: n MLP towers ending in a plain Linear to 1).
+mineral/agents/diffrl/utils.py:25-69 (soft_update, grad_norm, CriticDataset) and mineral/agents/diffrl/models.py:149-256
+(Critic / EnsembleCritic: MLP towers ending in a plain Linear to 1).
 """
 
 from collections import OrderedDict
@@ -64,46 +64,52 @@ def dataset_batches(obs, targets, batch_size):
     return [(o[s:min(s + batch_size, n)], t[s:min(s + batch_size, n)]) for s in range(0, n, batch_size)]
 
 
-def critic_shapes(obs_dim, units, n_critics):
+def critic_prefixes(n_critics, single=False):
+    """Parameter-name prefixes: `critics.<c>` for EnsembleCritic (models.py:197-214), `critic_mlp` for Critic (models.py:158)."""
+    return ['critic_mlp'] if single else [f'critics.{c}' for c in range(n_critics)]
+
+
+def critic_shapes(obs_dim, units, n_critics, single=False):
     res = []
-    for c in range(n_critics):
+    for pre in critic_prefixes(n_critics, single):
         in_f = obs_dim
         for i, u in enumerate(units):
             b = 3 * i
-            res += [(f'critics.{c}.mlp.{b}.weight', (u, in_f)), (f'critics.{c}.mlp.{b}.bias', (u,)), (f'critics.{c}.mlp.{b + 1}.weight', (u,)),
-                    (f'critics.{c}.mlp.{b + 1}.bias', (u,))]
+            res += [(f'{pre}.mlp.{b}.weight', (u, in_f)), (f'{pre}.mlp.{b}.bias', (u,)), (f'{pre}.mlp.{b + 1}.weight', (u,)),
+                    (f'{pre}.mlp.{b + 1}.bias', (u,))]
             in_f = u
         b = 3 * len(units)
-        res += [(f'critics.{c}.mlp.{b}.weight', (1, in_f)), (f'critics.{c}.mlp.{b}.bias', (1,))]
+        res += [(f'{pre}.mlp.{b}.weight', (1, in_f)), (f'{pre}.mlp.{b}.bias', (1,))]
     return res
 
 
-def critic_values(pc, obs, units, n_critics):
-    """EnsembleCritic.forward(return_type='all') (models.py:236-243): (n_critics, rows, 1)."""
-    cfg = TowerCfg(units)
+def critic_values(pc, obs, units, n_critics, act_type='SiLU', single=False):
+    """EnsembleCritic.forward(return_type='all') (models.py:236-243): (n_critics, rows, 1); with single=True the one tower of
+    Critic.forward (models.py:169-178), stacked the same way."""
+    cfg = TowerCfg(units, act_type=act_type)
     out = []
-    for c in range(n_critics):
-        h = P.mlp_forward(pc, f'critics.{c}', obs, cfg)
+    for pre in critic_prefixes(n_critics, single):
+        h = P.mlp_forward(pc, pre, obs, cfg)
         b = 3 * len(units)
-        out.append(F.linear(h, pc[f'critics.{c}.mlp.{b}.weight'], pc[f'critics.{c}.mlp.{b}.bias']))
+        out.append(F.linear(h, pc[f'{pre}.mlp.{b}.weight'], pc[f'{pre}.mlp.{b}.bias']))
     return torch.stack(out)
 
 
-def critic_loss(pc, obs, target, units, n_critics):
+def critic_loss(pc, obs, target, units, n_critics, act_type='SiLU', single=False):
     """compute_critic_loss (shac.py:868-874): mean over critics of the per-critic MSE."""
-    vs = critic_values(pc, obs, units, n_critics)
+    vs = critic_values(pc, obs, units, n_critics, act_type, single)
     return torch.stack([F.mse_loss(v.squeeze(-1), target) for v in vs]).mean()
 
 
 def update_critic(pc, opt_state, batches, units, n_critics, iterations, lr, optim_type='AdamW', betas=(0.7, 0.95), max_grad_norm=0.5,
-                  truncate_grads=True):
+                  truncate_grads=True, act_type='SiLU', single=False):
     """shac.py:827-866.  Returns per-iteration value_loss and mean gradient norms before / after the clip."""
     res = {'value_loss': [], 'grad_norm_before_clip/critic': [], 'grad_norm_after_clip/critic': []}
     for _ in range(iterations):
         total, before, after = 0.0, [], []
         for obs, tgt in batches:
             leaves = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in pc.items())
-            loss = critic_loss(leaves, obs, tgt, units, n_critics)
+            loss = critic_loss(leaves, obs, tgt, units, n_critics, act_type, single)
             grads = [g.nan_to_num(0.0, 0.0, 0.0) for g in torch.autograd.grad(loss, list(leaves.values()))]
             if truncate_grads:
                 before.append(torch.sqrt(sum(torch.sum(g ** 2) for g in grads)))

@@ -2,7 +2,8 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_shac.py [/root/reference]
 
-The reference's own `SHAC.compute_target_values`, `CriticDataset` and `SHAC.update_critic` are called on a namespace object
+The reference's own `SHAC.compute_target_values`, `CriticDataset` and `SHAC.update_critic` (on `EnsembleCritic` and on the single
+`Critic`) are called on a namespace object
 that carries the attributes those methods read (building the whole agent needs a differentiable simulator).  Inputs come
 from synth.py; the fixture holds outputs only.
 """
@@ -78,7 +79,33 @@ for case, (N, T, *_rest) in synth.SHAC_CASES.items():
 ent_path = os.path.join(HERE, 'g14_shac_entropy_targets.npz')
 np.savez_compressed(ent_path, **ent_out)
 print('wrote', ent_path, os.path.getsize(ent_path), 'bytes,', len(ent_out), 'arrays')
-if os.environ.get('GOLDEN_ONLY') == 'g14':
+
+# the single LayerNorm + ELU `Critic` of SHAC v1 (models.py:149-178) through the same update_critic
+v1_out = {}
+for case, (N, T, O, units, _one, n_batches, iters, optim_type, lr, max_norm) in synth.SHAC_V1_CASES.items():
+    obs, rew, done, nv = synth.shac_inputs(case)
+    ns = types.SimpleNamespace(critic_method='td-lambda', rew_buf=rew, gamma=0.99, lam=0.95, next_values=nv, done_mask=done, num_envs=N, device='cpu',
+                               horizon_len=T, target_values=torch.zeros(T, N))
+    ref_shac.SHAC.compute_target_values(ns)
+    targets = ns.target_values.clone()
+    critic = ref_models.Critic(O, 4, mlp_kwargs=dict(units=units, norm_type='LayerNorm', act_type='ELU'), weight_init='orthogonal')
+    critic.load_state_dict(synth.make_params(S.critic_shapes(O, units, 1, single=True), 63), strict=True)
+    with torch.no_grad():
+        v1_out[f'{case}_values0'] = critic(obs.reshape(-1, O)).numpy().copy()
+    optim = getattr(torch.optim, optim_type)(critic.parameters(), lr=lr, betas=(0.7, 0.95))
+    cfgd = MG.AttrDict.wrap(dict(truncate_grads=True, max_grad_norm=max_norm))
+    ns = types.SimpleNamespace(critic_iterations=iters, critic_optim=optim, critic=critic, encoder=lambda o: o['obs'], shac_config=cfgd)
+    ns.compute_critic_loss = lambda o, t, **kw: ref_shac.SHAC.compute_critic_loss(ns, o, t, **kw)
+    dataset = CriticDataset(N * T // n_batches, {'obs': obs}, targets, drop_last=False)
+    res = ref_shac.SHAC.update_critic(ns, dataset)
+    for k, v in res.items():
+        v1_out[f'{case}_{k.replace("/", "_")}'] = torch.stack(v).detach().numpy()
+    for k, v in critic.state_dict().items():
+        v1_out[f'{case}_critic.{k}'] = v.numpy().copy()
+v1_path = os.path.join(HERE, 'g15_shac_v1_critic.npz')
+np.savez_compressed(v1_path, **v1_out)
+print('wrote', v1_path, os.path.getsize(v1_path), 'bytes,', len(v1_out), 'arrays')
+if os.environ.get('GOLDEN_ONLY') in ('g14', 'g15'):
     sys.exit(0)
 
 path = os.path.join(HERE, 'g13_shac_critic.npz')

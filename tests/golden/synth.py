@@ -182,9 +182,16 @@ SHAC_CASES = {
 }
 
 
+# the single `Critic` of SHAC v1 (LayerNorm + ELU towers, cfgs/agent/DFlexAntSHAC.yaml); same tuple layout, n_critics = 1
+SHAC_V1_CASES = {
+    'ant_v1': (16, 8, 12, [64, 64], 1, 4, 3, 'Adam', 2e-3, 1.0),
+    'wide_v1': (12, 6, 8, [256, 128], 1, 5, 2, 'AdamW', 5e-4, 0.5),   # a layer of each backward kind (streamed / fused); short last batch
+}
+
+
 def shac_inputs(case, seed=17):
     """Rollout buffers of one SHAC epoch: obs (T,N,O), rewards, done mask, next values (T,N)."""
-    N, T, O = SHAC_CASES[case][:3]
+    N, T, O = {**SHAC_CASES, **SHAC_V1_CASES}[case][:3]
     obs = gaussianish((T, N, O), seed + 1)
     rew = gaussianish((T, N), seed + 2)
     done = (lcg_t((T, N), seed + 3, 1.0) + 0.5 < 0.15).float()

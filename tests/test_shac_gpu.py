@@ -154,3 +154,69 @@ def test_update_critic_vs_reference_run(case):
     soft_update(c, tgt, 0.2)
     for k, v in tgt.state_dict().items():
         assert torch.allclose(v.cpu(), torch.from_numpy(G[f'{case}_target.{k}']), rtol=2e-3, atol=2e-4), k
+
+
+def make_critic_v1(O, units, seed):
+    from mineral_amd.agents.diffrl import Critic
+    c = Critic(O, None, mlp_kwargs=dict(units=units, norm_type='LayerNorm', act_type='ELU'), device=DEV)
+    pc = synth.make_params(S.critic_shapes(O, units, 1, single=True), seed)
+    c.load_state_dict(pc)
+    return c, pc
+
+
+@pytest.mark.parametrize('rows,O,units', [(300, 40, [256, 128]), (64, 8, [64, 64]), (1000, 60, [512, 256, 128]), (9000, 12, [128, 32])])
+def test_layernorm_elu_critic_values_and_gradient_vs_oracle(rows, O, units):
+    """The single LayerNorm + ELU `Critic` (models.py:149-178): values, return types and the MSE gradient."""
+    from mineral_amd.agents.diffrl import CriticLearner
+    c, pc = make_critic_v1(O, units, 35)
+    assert list(c.state_dict()) == [k for k, _ in S.critic_shapes(O, units, 1, single=True)]
+    obs = synth.gaussianish((rows, O), 3)
+    tgt = synth.gaussianish((rows,), 4) * 2.0
+    want_v = S.critic_values(pc, obs, units, 1, 'ELU', single=True)[0]
+    got_v = c(obs.to(DEV))
+    assert got_v.shape == want_v.shape
+    assert torch.allclose(got_v.cpu(), want_v, rtol=1e-4, atol=2e-5)
+    allv = c(obs.to(DEV), return_type='all')
+    assert isinstance(allv, list) and len(allv) == 1 and torch.equal(allv[0], got_v)
+    vmin, vavg = c(obs.to(DEV), return_type='min_and_avg')
+    assert torch.equal(vmin, got_v) and torch.equal(vavg, got_v) and vmin.data_ptr() != vavg.data_ptr()
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    loss = S.critic_loss(leaves, obs, tgt, units, 1, 'ELU', single=True)
+    grads = dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+    learner = CriticLearner(c)
+    got_loss = learner.compute_critic_loss({'obs': obs.to(DEV)}, tgt.to(DEV))
+    assert abs(got_loss.item() - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-6
+    got = c.views_of(learner.grads)
+    for k, g in grads.items():
+        # fp32 GEMMs with a different summation order: 3e-4 of the tensor's largest gradient
+        assert (got[k].cpu() - g).abs().max().item() <= 3e-4 * g.abs().max().item() + 1e-7, k
+
+
+@pytest.mark.parametrize('case', sorted(synth.SHAC_V1_CASES))
+def test_update_critic_layernorm_elu_vs_reference_run(case):
+    from mineral_amd.agents.diffrl import CriticDataset, CriticLearner
+    G1 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g15_shac_v1_critic.npz'))
+    N, T, O, units, _one, n_batches, iters, optim_type, lr, max_norm = synth.SHAC_V1_CASES[case]
+    obs, rew, done, nv = synth.shac_inputs(case)
+    targets = targets_hip(rew, done, nv, 0.99, 0.95, 'td-lambda').to(DEV)
+    ds = CriticDataset(N * T // n_batches, {'obs': obs.to(DEV)}, targets, drop_last=False)
+    c, _ = make_critic_v1(O, units, 63)
+    assert np.allclose(c(obs.reshape(-1, O).to(DEV)).cpu().numpy(), G1[f'{case}_values0'], rtol=1e-4, atol=2e-5)
+    learner = CriticLearner(c, optim_type, dict(lr=lr, betas=(0.7, 0.95)), critic_iterations=iters, max_grad_norm=max_norm)
+    res = learner.update_critic(ds)
+    for k, v in res.items():
+        assert np.allclose(torch.stack(v).cpu().numpy(), G1[f'{case}_{k.replace("/", "_")}'], rtol=1e-3, atol=1e-5), k
+    for k, v in c.state_dict().items():
+        # tolerances as for the SiLU ensemble: Adam's normalisation amplifies gradient rounding on small entries
+        assert torch.allclose(v.cpu(), torch.from_numpy(G1[f'{case}_critic.{k}']), rtol=2e-3, atol=2e-4), k
+
+
+def test_critic_rejects_unknown_activation():
+    from mineral_amd import _hip
+    from mineral_amd.agents.diffrl import Critic
+    with pytest.raises(NotImplementedError):
+        Critic(12, None, mlp_kwargs=dict(units=[64, 64], norm_type='LayerNorm', act_type='Tanh'), device=DEV)
+    net = _hip.make_critic_net(12, 1, [64, 64])
+    net.act_type = 7
+    assert _hip.lib().mrl_critic_param_count(net) < 0

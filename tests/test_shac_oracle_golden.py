@@ -60,3 +60,22 @@ def test_entropy_target_values_bit_exact(case):
             for scale in (False, True):
                 got = S.target_values_with_entropy(rew, done, nv, -1.0 * logp, 0.05, 0.99, 0.95, method, offset, scale, -3.0)
                 assert np.array_equal(got.numpy(), GE[f'{case}_{method}_o{int(offset)}s{int(scale)}']), (method, offset, scale)
+
+
+@pytest.mark.parametrize('case', sorted(synth.SHAC_V1_CASES))
+def test_update_critic_single_layernorm_elu(case):
+    """The single `Critic` of SHAC v1 (models.py:149-178, LayerNorm + ELU) through update_critic, against the reference's run."""
+    G1 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g15_shac_v1_critic.npz'))
+    N, T, O, units, _one, n_batches, iters, optim_type, lr, max_norm = synth.SHAC_V1_CASES[case]
+    obs, rew, done, nv = synth.shac_inputs(case)
+    targets = S.target_values(rew, done, nv, 0.99, 0.95)
+    pc = synth.make_params(S.critic_shapes(O, units, 1, single=True), 63)
+    v0 = S.critic_values(pc, obs.reshape(-1, O), units, 1, 'ELU', single=True)[0]
+    assert np.allclose(v0.numpy(), G1[f'{case}_values0'], rtol=1e-5, atol=1e-6)
+    st = P.adam_state_init(pc)
+    res = S.update_critic(pc, st, S.dataset_batches(obs, targets, N * T // n_batches), units, 1, iters, lr, optim_type, (0.7, 0.95), max_norm,
+                          act_type='ELU', single=True)
+    for k, v in res.items():
+        assert np.allclose(torch.stack(v).numpy(), G1[f'{case}_{k.replace("/", "_")}'], rtol=2e-5, atol=1e-6), k
+    for k, v in pc.items():
+        assert torch.allclose(v, torch.from_numpy(G1[f'{case}_critic.{k}']), rtol=2e-5, atol=2e-6), k
