@@ -1,5 +1,6 @@
 """Critic side of SHAC on the device: TD(lambda) target scan and `update_critic` (critic_iterations x num_critic_batches
-optimizer steps), at the reference's DFlexAntSHAC2 shape (64 envs) and at 4096 envs, with the CPU oracle timed beside it.
+optimizer steps), at the reference's DFlexAntSHAC2 shape (64 envs), at 4096 envs, and with the single LayerNorm+ELU critic of
+DFlexAntSHAC.yaml at 8192 envs; the CPU oracle is timed beside it.
 
     python tools/shac_bench.py [out.json]
 """
@@ -18,16 +19,20 @@ T, O, UNITS, NC, NB, ITERS = 32, 64, [64, 64], 2, 4, 16     # cfgs/agent/DFlexAn
 DEV = 'cuda:0'
 
 
-def device_case(N):
-    from mineral_amd.agents.diffrl import CriticDataset, CriticLearner, EnsembleCritic, compute_target_values
+def device_case(N, v1=False):
+    from mineral_amd.agents.diffrl import Critic, CriticDataset, CriticLearner, EnsembleCritic, compute_target_values
     g = torch.Generator(device=DEV).manual_seed(0)
     obs = torch.randn(T, N, O, device=DEV, generator=g)
     rew = torch.randn(T, N, device=DEV, generator=g)
     nv = torch.randn(T, N, device=DEV, generator=g)
     done = (torch.rand(T, N, device=DEV, generator=g) < 0.02).float()
-    critic = EnsembleCritic(O, None, n_critics=NC, mlp_kwargs=dict(units=UNITS, norm_type='LayerNorm', act_type='SiLU'), weight_init='orthogonalg1',
-                            device=DEV)
-    learner = CriticLearner(critic, 'AdamW', dict(lr=5e-4, betas=(0.7, 0.95)), critic_iterations=ITERS, max_grad_norm=0.5, no_target_critic=True)
+    if v1:   # cfgs/agent/DFlexAntSHAC.yaml:19-52
+        critic = Critic(O, None, mlp_kwargs=dict(units=UNITS, norm_type='LayerNorm', act_type='ELU'), device=DEV)
+        learner = CriticLearner(critic, 'Adam', dict(lr=2e-3, betas=(0.7, 0.95)), critic_iterations=ITERS, max_grad_norm=1.0, target_critic_alpha=0.2)
+    else:
+        critic = EnsembleCritic(O, None, n_critics=NC, mlp_kwargs=dict(units=UNITS, norm_type='LayerNorm', act_type='SiLU'), weight_init='orthogonalg1',
+                                device=DEV)
+        learner = CriticLearner(critic, 'AdamW', dict(lr=5e-4, betas=(0.7, 0.95)), critic_iterations=ITERS, max_grad_norm=0.5, no_target_critic=True)
     out = torch.empty_like(rew)
     for _ in range(3):
         compute_target_values(rew, done, nv, 0.99, 0.95, 'td-lambda', out=out)
@@ -44,9 +49,10 @@ def device_case(N):
     t0 = time.perf_counter()
     for _ in range(3):
         learner.update_critic(ds)
+        learner.update_target()
     torch.cuda.synchronize()
     t_upd = (time.perf_counter() - t0) / 3
-    return {'num_envs': N, 'samples': N * T, 'tdlambda_us': t_scan * 1e6, 'tdlambda_GBps': 16.0 * N * T / t_scan / 1e9,
+    return {'num_envs': N, 'critic': 'Critic LayerNorm+ELU' if v1 else 'EnsembleCritic x2 LayerNorm+SiLU', 'samples': N * T, 'tdlambda_us': t_scan * 1e6, 'tdlambda_GBps': 16.0 * N * T / t_scan / 1e9,
             'update_critic_ms': t_upd * 1e3, 'optimizer_steps': ITERS * NB, 'critic_samples_per_s': N * T * ITERS / t_upd}
 
 
@@ -70,7 +76,7 @@ def scan_case(N):
     return {'num_envs': N, 'tdlambda_us': t * 1e6, 'tdlambda_GBps': 16.0 * N * T / t / 1e9, 'bound': 'hbm', 'peak_GBps': 8000}
 
 
-def cpu_case(N, threads):
+def cpu_case(N, threads, v1=False):
     import synth
     from oracle import ppo_oracle as P
     from oracle import shac_oracle as S
@@ -81,20 +87,24 @@ def cpu_case(N, threads):
     t0 = time.perf_counter()
     tgt = S.target_values(rew, done, nv, 0.99, 0.95)
     t_scan = time.perf_counter() - t0
-    pc = synth.make_params(S.critic_shapes(O, UNITS, NC), 5)
+    pc = synth.make_params(S.critic_shapes(O, UNITS, 1 if v1 else NC, single=v1), 5)
     st = P.adam_state_init(pc)
     batches = S.dataset_batches(obs, tgt, N * T // NB)
     t0 = time.perf_counter()
-    S.update_critic(pc, st, batches, UNITS, NC, ITERS, 5e-4, 'AdamW', (0.7, 0.95), 0.5)
+    if v1:
+        S.update_critic(pc, st, batches, UNITS, 1, ITERS, 2e-3, 'Adam', (0.7, 0.95), 1.0, act_type='ELU', single=True)
+    else:
+        S.update_critic(pc, st, batches, UNITS, NC, ITERS, 5e-4, 'AdamW', (0.7, 0.95), 0.5)
     t_upd = time.perf_counter() - t0
-    return {'num_envs': N, 'cores': threads, 'kind': 'port', 'tdlambda_us': t_scan * 1e6, 'update_critic_ms': t_upd * 1e3,
+    return {'num_envs': N, 'critic': 'Critic LayerNorm+ELU' if v1 else 'EnsembleCritic x2 LayerNorm+SiLU', 'cores': threads, 'kind': 'port', 'tdlambda_us': t_scan * 1e6, 'update_critic_ms': t_upd * 1e3,
             'critic_samples_per_s': N * T * ITERS / t_upd}
 
 
 def main():
-    res = {'metric': 'SHAC critic side: update_critic samples/s and TD(lambda) scan, ensemble of 2 critics [64,64] LayerNorm+SiLU',
-           'device': [device_case(64), device_case(4096)], 'scan': scan_case(1 << 20),
-           'cpu_baseline': [cpu_case(64, 1), cpu_case(4096, min(16, os.cpu_count() or 1))]}
+    cores = min(16, os.cpu_count() or 1)
+    res = {'metric': 'SHAC critic side: update_critic samples/s and TD(lambda) scan; critics [64,64]',
+           'device': [device_case(64), device_case(4096), device_case(8192, v1=True)], 'scan': scan_case(1 << 20),
+           'cpu_baseline': [cpu_case(64, 1), cpu_case(4096, cores), cpu_case(8192, cores, v1=True)]}
     text = json.dumps(res, indent=1)
     print(text)
     if len(sys.argv) > 1 and not sys.argv[1].startswith('-'):
