@@ -2,6 +2,7 @@
 // sequences that drive the fp32 MFMA GEMM family of gemm.hip.h.  gfx950 only.
 #include "../../include/mineral_ppo.h"
 #include "gemm.hip.h"
+#include "wgrad_split.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -369,10 +370,47 @@ constexpr int MRL_SMALL_WGN = 8;
 
 static inline unsigned slab_grid(int n_groups, int group_size) { return (unsigned)(cdiv(n_groups, 8) * 8 * group_size); }
 
+// The 128 x 128-tile weight gradients whose sizes are whole tiles run on the bf16 matrix cores from exact three-term
+// splits of the fp32 operands (wgrad_split.hip.h): same grid, splits and slabs as the fp32 kernel it replaces.
+constexpr int64_t MRL_WGRAD_SPLIT_MIN_ROWS = 8192;   // below this the launch is latency-bound and the fp32 kernel's shorter prologue wins
+
+static bool wgrad_split_eligible(const GemmP& p, const WgradPlan& w, int towers) {
+  if (w.bm != 128 || w.bn != 128 || p.M % 128 || p.N % 128 || p.K < MRL_WGRAD_SPLIT_MIN_ROWS) return false;
+  if (p.lda % 4 || p.ldb % 4) return false;
+  for (int z = 0; z < towers; ++z)
+    if (p.Nt[z] && p.Nt[z] != p.N) return false;
+  return true;
+}
+
+template <int PRO>
+static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
+  static int cls = [] {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "mrl::wgrad_split_kernel<%d>", PRO);
+    return prof_register(nm);
+  }();
+  const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+  }
+  hipLaunchKernelGGL((wgrad_split_kernel<PRO>), grid, dim3(256), 0, s, p);
+  if (timed) {
+    (void)hipEventRecord(e1, s);
+    ProfClass& c = g_prof[cls];
+    c.ev.emplace_back(e0, e1);
+    c.flops += 2.0 * p.M * (double)p.N * (double)p.K * grid.z;   // algorithmic FLOPs: one multiply-add per (m, n, row)
+  }
+}
+
 template <int PRO>
 static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
   dim3 grid(slab_grid(w.nsplit, w.tiles_m * w.tiles_n), 1, towers);
-  if (w.bm == 32)
+  if (wgrad_split_eligible(p, w, towers))
+    launch_wgrad_split<PRO>(p, grid, s);
+  else if (w.bm == 32)
     launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else if (w.bn == 64)
     launch_gemm<128, 64, 16, 4, 1, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);

@@ -1,0 +1,240 @@
+// Weight-gradient GEMM of the wide layers on the bf16 matrix cores of gfx950, with fp32 accuracy.
+//
+//   slab[split][m][n] = sum over the split's batch rows k of A[k][m] * f(B[k][n])      A = dZ, B = the layer input, f = prologue
+//
+// Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by truncation; bf16 has
+// the exponent range of fp32, so nothing under- or overflows), and each product is accumulated in fp32 from the six terms
+// hh, hm, mh, mm, hl, lh; the three dropped terms are below 2^-24 of |a*b|, the rounding of an fp32 product itself.  Against
+// an fp64 sum the result is closer than a sequential fp32 fma chain (2e-8 against 1.5e-7 of sum|a*b| over 32,768 rows,
+// tools/bf16x3_split_probe.hip).  Six v_mfma_f32_32x32x16_bf16 (16 k each) replace eight v_mfma_f32_32x32x2_f32 twice as long.
+//
+// Tiles: 128 x 128 per 256-thread block (2 x 2 waves of 64 x 64), 16 batch rows per step.  Each plane of an operand is an
+// LDS image [16 rows][128 columns] of bf16 in the operand's own row-major order; the k-contiguous MFMA fragments come out of
+// it through ds_read_b64_tr_b16.  Per step the fragments of step st are read while the MFMAs of step st-1 run from the
+// other fragment set and the operands of step st+1 are split and written to the other LDS stage; global loads run three
+// steps ahead.  One barrier per step.
+//
+// Grid, split ranges and the slab layout are those of the EPI_SLAB launches of gemm_kernel with group_mode 1, so the plan,
+// the workspace and the slab reduction do not change.  Requires M and N to be multiples of 128.
+#pragma once
+
+#include <type_traits>
+
+namespace mrl {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace wsplit {
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int ROWB = 320;           // bytes per row of a plane: 128 bf16 + 64 B, so that four consecutive rows cover the 64 banks
+constexpr int PLANE = BK * ROWB;    // 5,120 B
+constexpr int OPER = 3 * PLANE;     // three planes per operand
+constexpr int STAGE = 2 * OPER;     // A and B of one step: 30,720 B; two stages
+
+// x (4 floats) -> three packed bf16 quadruples with x = h + m + l exactly
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned xb = __float_as_uint(x[e]);
+    hb[e] = xb & 0xffff0000u;
+    const float r1 = x[e] - __uint_as_float(hb[e]);
+    mb[e] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb[e]);
+    lb[e] = __float_as_uint(r2);                      // at most 8 significant bits are left: its upper half is exact
+  }
+  // low half = upper 16 bits of the even element, high half = upper 16 bits of the odd one
+  h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+  h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+  m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+  m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+  l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
+  l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+}
+
+// Two transposed 4-row blocks (rows k .. k+3 and k+4 .. k+7 of this lane's column) make one MFMA fragment.  Every lane of
+// the wave must take part (the gather crosses lanes): callers keep the whole block active.
+__device__ __forceinline__ bf16x8 tr_frag(const char* base) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * ROWB));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+}  // namespace wsplit
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
+  using namespace wsplit;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tw = blockIdx.z;
+  // block -> (split, tile) as in gemm_kernel: the tiles of one split get ids that differ by 8 and share an XCD's L2
+  const int gsz = p.m_tiles * p.n_tiles;
+  const int lin = blockIdx.x, tq = lin >> 3, j = tq % gsz;
+  const int split = (tq / gsz) * 8 + (lin & 7);
+  if (split >= p.n_groups) return;                     // padding blocks of the last octet of splits (whole blocks leave)
+  const int m0 = (j % p.m_tiles) * BM, n0 = (j / p.m_tiles) * BN;
+  const int kfull = p.Kt[tw] ? p.Kt[tw] : p.K;
+  const int kbeg = split * p.ksplit, kend = min(kfull, kbeg + p.ksplit);
+  const int nsteps = (kend - kbeg + BK - 1) / BK;
+  const float* __restrict__ Ag = p.A[tw];
+  const float* __restrict__ Bg = p.B[tw];
+
+  // staging map: chunk c (4 columns) of rows (t >> 5) and (t >> 5) + 8 of each 16-row step
+  const int c = t & 31, kr = t >> 5;
+  constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU || PRO == PRO_LNELU;
+  f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (PRO_VEC) {                              // the feature index of a B column does not change along the reduction
+    pv0 = *reinterpret_cast<const f32x4*>(p.pro0[tw] + n0 + 4 * c);
+    pv1 = *reinterpret_cast<const f32x4*>(p.pro1[tw] + n0 + 4 * c);
+  }
+  auto transform = [&](f32x4 v) {
+    f32x4 o = v;
+    if constexpr (PRO == PRO_NORM) {                    // mineral/common/normalizers.py:65-68
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf((v[e] - pv0[e]) / pv1[e], p.clamp_lo), p.clamp_hi);
+    } else if constexpr (PRO == PRO_ELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : __builtin_amdgcn_exp2f(1.44269504088896340736f * v[e]) - 1.0f;
+    } else if constexpr (PRO == PRO_LNELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = v[e] * pv0[e] + pv1[e];
+        o[e] = y > 0.f ? y : __builtin_amdgcn_exp2f(1.44269504088896340736f * y) - 1.0f;
+      }
+    } else if constexpr (PRO == PRO_LNSILU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = v[e] * pv0[e] + pv1[e];
+        o[e] = y * sigmoid_fast(y);
+      }
+    }
+    return o;
+  };
+
+  f32x4 ra[2][2], rb[2][2];                             // [register set = step parity][row]
+  auto gload = [&](int st, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const int k = kbeg + st * BK + kr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t kk = min(k + 8 * i, kfull - 1);     // rows past the end are loaded clamped and zeroed when staged
+      ra[S][i] = *reinterpret_cast<const f32x4*>(Ag + kk * p.lda + m0 + 4 * c);
+      rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + kk * p.ldb + n0 + 4 * c);
+    }
+  };
+  auto stage = [&](int st, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    char* buf = lds + S * STAGE;
+    const int k = kbeg + st * BK + kr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = k + 8 * i < kend;
+      u32x2 h, m, l;
+      char* q = buf + (kr + 8 * i) * ROWB + c * 8;
+      split4(ok ? ra[S][i] : zero, h, m, l);
+      *reinterpret_cast<u32x2*>(q) = h;
+      *reinterpret_cast<u32x2*>(q + PLANE) = m;
+      *reinterpret_cast<u32x2*>(q + 2 * PLANE) = l;
+      f32x4 v = rb[S][i];
+      if constexpr (PRO != PRO_NONE) v = transform(v);
+      split4(ok ? v : zero, h, m, l);
+      *reinterpret_cast<u32x2*>(q + OPER) = h;
+      *reinterpret_cast<u32x2*>(q + OPER + PLANE) = m;
+      *reinterpret_cast<u32x2*>(q + OPER + 2 * PLANE) = l;
+    }
+  };
+
+  // fragment map of v_mfma_f32_32x32x16_bf16 through transposed reads: 16-lane group g takes columns 16 (g & 1) .. +15 and
+  // rows 8 (g >> 1) .. +7 of the step; lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int frag_off = (8 * (g >> 1) + q4) * ROWB + (16 * (g & 1) + 4 * p4) * 2;
+  const int fa = frag_off + (wm * 64) * 2;
+  const int fb = OPER + frag_off + (wn * 64) * 2;
+  bf16x8 fra[2][2][3], frb[2][2][3];                   // [fragment set = step parity][tile][plane]
+  auto frags = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const char* cur = lds + S * STAGE;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fra[S][i][pl] = tr_frag(cur + fa + pl * PLANE + i * 64);
+        frb[S][i][pl] = tr_frag(cur + fb + pl * PLANE + i * 64);
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+  auto mfmas = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    // six terms per accumulator, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[S][i][TA[term]], frb[S][jn][TB[term]], acc[i][jn], 0, 0, 0);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // Step st (parity P): read the fragments of step st from stage P, run the MFMAs of step st-1 from the other fragment set,
+  // split the operands of step st+1 (register set P^1) into stage P^1, whose fragments were read a step ago, then refill
+  // that register set with step st+3.  Steps past the end of the split stage zeros and are never multiplied.
+  auto steady = [&](int st, auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    using Q = std::integral_constant<int, P ^ 1>;
+    frags(PAR);
+    mfmas(Q{});
+    stage(st + 1, Q{});
+    gload(st + 3, Q{});
+    __syncthreads();
+  };
+
+  gload(0, I0{});
+  gload(1, I1{});
+  stage(0, I0{});
+  gload(2, I0{});
+  __syncthreads();
+  frags(I0{});
+  stage(1, I1{});
+  gload(3, I1{});
+  __syncthreads();
+  int st = 1;
+  for (; st + 1 < nsteps; st += 2) {
+    steady(st, I1{});
+    steady(st + 1, I0{});
+  }
+  if (st < nsteps) {
+    steady(st, I1{});
+    mfmas(I1{});
+  } else {
+    mfmas(I0{});
+  }
+
+  float* out = p.out[tw] + (int64_t)split * p.M * p.ldo;
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + col] = acc[i][jn][r];
+      }
+}
+
+}  // namespace mrl

@@ -53,6 +53,7 @@ NETS = {
     'elu_wide': dict(obs=20, act=3, units=[256, 64], norm=None, actf='ELU', fixed=True),
     'elu_head': dict(obs=64, act=12, units=[512, 128], norm=None, actf='ELU', fixed=False),
     'ln_fixed': dict(obs=64, act=12, units=[128, 64], fixed=True),
+    'obs128': dict(obs=128, act=12, units=[128, 128]),
 }
 
 
@@ -255,6 +256,11 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('elu_wide', 50, 8, 200, 'normal', 0, 'bound'),
     ('elu_head', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
     ('ln_fixed', 64, 8, 256, 'normal', 0, 'bound'),
+    # minibatches of 8192 rows and more take the weight gradients of whole-128 layers through the split-bf16 kernel; 8328 rows
+    # end in a partial 16-row step
+    ('full', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
 ])
 def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
     spec = NETS[net]

@@ -164,7 +164,8 @@ def make_critic_v1(O, units, seed):
     return c, pc
 
 
-@pytest.mark.parametrize('rows,O,units', [(300, 40, [256, 128]), (64, 8, [64, 64]), (1000, 60, [512, 256, 128]), (9000, 12, [128, 32])])
+@pytest.mark.parametrize('rows,O,units', [(300, 40, [256, 128]), (64, 8, [64, 64]), (1000, 60, [512, 256, 128]), (9000, 12, [128, 32]),
+                                          (9000, 12, [256, 128]), (8200, 128, [128, 64])])   # the last two: split-bf16 weight gradients
 def test_layernorm_elu_critic_values_and_gradient_vs_oracle(rows, O, units):
     """The single LayerNorm + ELU `Critic` (models.py:149-178): values, return types and the MSE gradient."""
     from mineral_amd.agents.diffrl import CriticLearner
