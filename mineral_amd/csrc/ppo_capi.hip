@@ -2,7 +2,7 @@
 // sequences that drive the fp32 MFMA GEMM family of gemm.hip.h.  gfx950 only.
 #include "../../include/mineral_ppo.h"
 #include "gemm.hip.h"
-#include "wgrad_split.hip.h"
+#include "split_bf16.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -371,7 +371,7 @@ constexpr int MRL_SMALL_WGN = 8;
 static inline unsigned slab_grid(int n_groups, int group_size) { return (unsigned)(cdiv(n_groups, 8) * 8 * group_size); }
 
 // The 128 x 128-tile weight gradients whose sizes are whole tiles run on the bf16 matrix cores from exact three-term
-// splits of the fp32 operands (wgrad_split.hip.h): same grid, splits and slabs as the fp32 kernel it replaces.
+// splits of the fp32 operands (split_bf16.hip.h): same grid, splits and slabs as the fp32 kernel it replaces.
 constexpr int64_t MRL_WGRAD_SPLIT_MIN_ROWS = 8192;   // below this the launch is latency-bound and the fp32 kernel's shorter prologue wins
 
 static bool wgrad_split_eligible(const GemmP& p, const WgradPlan& w, int towers) {
@@ -402,6 +402,25 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     ProfClass& c = g_prof[cls];
     c.ev.emplace_back(e0, e1);
     c.flops += 2.0 * p.M * (double)p.N * (double)p.K * grid.z;   // algorithmic FLOPs: one multiply-add per (m, n, row)
+  }
+}
+
+// input gradients of the wide layers (N a multiple of 128, K of 16) through dgrad_split_kernel; same grid as the fp32 launch
+static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
+  static int cls = prof_register("mrl::dgrad_split_kernel");
+  const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+  }
+  hipLaunchKernelGGL(dgrad_split_kernel, grid, dim3(256), 0, s, p);
+  if (timed) {
+    (void)hipEventRecord(e1, s);
+    ProfClass& c = g_prof[cls];
+    c.ev.emplace_back(e0, e1);
+    c.flops += 2.0 * p.M * (double)p.N * (double)p.K * grid.z;
   }
 }
 
@@ -1336,7 +1355,9 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
         launch_gemm<32, 128, 16, 1, 4, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
       } else {
         p.m_tiles = (int)cdiv(mb, 128); p.n_groups = p.m_tiles;
-        launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+        const dim3 grid(slab_grid(p.n_groups, p.n_tiles), 1, towers);
+        if (l != last && kdim % 16 == 0) launch_dgrad_split(p, grid, s);   // A = dZ of the layer above, all K columns valid
+        else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, grid, s);
       }
       LnBwdArgs a;
       memset(&a, 0, sizeof(a));

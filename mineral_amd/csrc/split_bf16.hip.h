@@ -1,6 +1,7 @@
-// Weight-gradient GEMM of the wide layers on the bf16 matrix cores of gfx950, with fp32 accuracy.
+// fp32-accurate GEMMs on the bf16 matrix cores of gfx950: the weight gradients and the input gradients of the wide layers.
 //
-//   slab[split][m][n] = sum over the split's batch rows k of A[k][m] * f(B[k][n])      A = dZ, B = the layer input, f = prologue
+//   wgrad:  slab[split][m][n] = sum over the split's batch rows k of A[k][m] * f(B[k][n])    A = dZ, B = the layer input, f = prologue
+//   dgrad:  out[m][n] = sum_k A[m][k] * B[k][n]                                              A = dZ of the layer above, B = its weights
 //
 // Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by truncation; bf16 has
 // the exponent range of fp32, so nothing under- or overflows), and each product is accumulated in fp32 from the six terms
@@ -8,14 +9,15 @@
 // an fp64 sum the result is closer than a sequential fp32 fma chain (2e-8 against 1.5e-7 of sum|a*b| over 32,768 rows,
 // tools/bf16x3_split_probe.hip).  Six v_mfma_f32_32x32x16_bf16 (16 k each) replace eight v_mfma_f32_32x32x2_f32 twice as long.
 //
-// Tiles: 128 x 128 per 256-thread block (2 x 2 waves of 64 x 64), 16 batch rows per step.  Each plane of an operand is an
-// LDS image [16 rows][128 columns] of bf16 in the operand's own row-major order; the k-contiguous MFMA fragments come out of
-// it through ds_read_b64_tr_b16.  Per step the fragments of step st are read while the MFMAs of step st-1 run from the
-// other fragment set and the operands of step st+1 are split and written to the other LDS stage; global loads run three
-// steps ahead.  One barrier per step.
+// Tiles: 128 x 128 per 256-thread block (2 x 2 waves of 64 x 64), 16 reduction indices per step.  An operand whose rows are
+// the reduction index keeps each plane as an LDS image [16 rows][128 columns] of bf16 in its own row-major order, and the
+// k-contiguous MFMA fragments come out of it through ds_read_b64_tr_b16; an operand with the reduction index along its rows
+// keeps [128 rows][16 k] and is read with ds_read_b128.  Per step the fragments of step st are read while the MFMAs of step
+// st-1 run from the other fragment set and the operands of step st+1 are split and written to the other LDS stage; global
+// loads run three steps ahead.  One barrier per step.
 //
-// Grid, split ranges and the slab layout are those of the EPI_SLAB launches of gemm_kernel with group_mode 1, so the plan,
-// the workspace and the slab reduction do not change.  Requires M and N to be multiples of 128.
+// Grids, split ranges and output layouts are those of the EPI_SLAB launches of gemm_kernel (group_mode 1 for wgrad, 0 for
+// dgrad), so plans, workspace and the slab reduction do not change.  Both need N to be a multiple of 128; wgrad also M.
 #pragma once
 
 #include <type_traits>
@@ -234,6 +236,147 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + col] = acc[i][jn][r];
+      }
+}
+
+// Input gradient of a wide layer: out[m][n] = sum_k A[m][k] B[k][n] with A = dZ of the layer above ([rows][K], K along the
+// row) and B = that layer's weights ([K][N]).  K must be a multiple of 16; rows past M are computed from clamped loads and
+// not stored.
+__global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
+  using namespace wsplit;
+  constexpr int APLANE = BM * 32;          // [128 rows][16 k] bf16, 32 B per row; the two 16-byte halves of a row swap places
+  constexpr int AOPER = 3 * APLANE;        // on every other group of 8 rows, which spreads a quarter-wave's 16-byte reads over all banks
+  constexpr int DSTAGE = AOPER + OPER;     // 27,648 B; two stages
+  __shared__ __attribute__((aligned(16))) char lds[2 * DSTAGE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tw = blockIdx.z;
+  // block -> (row tile, column tile): the column tiles of one row tile get ids that differ by 8 and share an XCD's L2
+  const int gsz = p.n_tiles;
+  const int lin = blockIdx.x, tq = lin >> 3, j = tq % gsz;
+  const int grp = (tq / gsz) * 8 + (lin & 7);
+  if (grp >= p.n_groups) return;                       // padding blocks of the last octet of row tiles (whole blocks leave)
+  const int m0 = grp * BM, n0 = j * BN;
+  const int K = p.Kt[tw] ? p.Kt[tw] : p.K;
+  const int nsteps = K / BK;
+  const float* __restrict__ Ag = p.A[tw];
+  const float* __restrict__ Bg = p.B[tw];
+
+  // A staging map: 4-float chunk ca of rows (t >> 2) and (t >> 2) + 64; B: chunk c of rows (t >> 5) and (t >> 5) + 8
+  const int ca = t & 3, rowa = t >> 2;
+  const int c = t & 31, kr = t >> 5;
+  auto a_off = [](int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) * 16); };
+  f32x4 ra[2][2], rb[2][2];                             // [register set = step parity][row]
+  auto gload = [&](int st, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const int k0 = min(st * BK, K - BK);                // steps past the end re-read the last one; they are never multiplied
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t row = min(m0 + rowa + 64 * i, p.M - 1);
+      ra[S][i] = *reinterpret_cast<const f32x4*>(Ag + row * p.lda + k0 + 4 * ca);
+      rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)(k0 + kr + 8 * i) * p.ldb + n0 + 4 * c);
+    }
+  };
+  auto stage = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    char* buf = lds + S * DSTAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x2 h, m, l;
+      char* qa = buf + a_off(rowa + 64 * i, ca >> 1) + (ca & 1) * 8;
+      split4(ra[S][i], h, m, l);
+      *reinterpret_cast<u32x2*>(qa) = h;
+      *reinterpret_cast<u32x2*>(qa + APLANE) = m;
+      *reinterpret_cast<u32x2*>(qa + 2 * APLANE) = l;
+      char* qb = buf + AOPER + (kr + 8 * i) * ROWB + c * 8;
+      split4(rb[S][i], h, m, l);
+      *reinterpret_cast<u32x2*>(qb) = h;
+      *reinterpret_cast<u32x2*>(qb + PLANE) = m;
+      *reinterpret_cast<u32x2*>(qb + 2 * PLANE) = l;
+    }
+  };
+
+  // fragments: A rows straight (lane l32 = row, half-wave = k half), B through transposed reads as in the weight gradient
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int fb = AOPER + (8 * (g >> 1) + q4) * ROWB + (16 * (g & 1) + 4 * p4) * 2 + (wn * 64) * 2;
+  int fa[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = a_off(wm * 64 + i * 32 + l32, hh);
+  bf16x8 fra[2][2][3], frb[2][2][3];                   // [fragment set = step parity][tile][plane]
+  auto frags = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const char* cur = lds + S * DSTAGE;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fra[S][i][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * APLANE + fa[i]);
+        frb[S][i][pl] = tr_frag(cur + fb + pl * PLANE + i * 64);
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+  auto mfmas = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[S][i][TA[term]], frb[S][jn][TB[term]], acc[i][jn], 0, 0, 0);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  auto steady = [&](int st, auto PAR) {                 // the pipeline of wgrad_split_kernel
+    constexpr int P = decltype(PAR)::value;
+    using Q = std::integral_constant<int, P ^ 1>;
+    frags(PAR);
+    mfmas(Q{});
+    stage(Q{});
+    gload(st + 3, Q{});
+    __syncthreads();
+  };
+
+  gload(0, I0{});
+  gload(1, I1{});
+  stage(I0{});
+  gload(2, I0{});
+  __syncthreads();
+  frags(I0{});
+  stage(I1{});
+  gload(3, I1{});
+  __syncthreads();
+  int st = 1;
+  for (; st + 1 < nsteps; st += 2) {
+    steady(st, I1{});
+    steady(st + 1, I0{});
+  }
+  if (st < nsteps) {
+    steady(st, I1{});
+    mfmas(I1{});
+  } else {
+    mfmas(I0{});
+  }
+
+  float* out = p.out[tw];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < p.M) out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
       }
 }
 
