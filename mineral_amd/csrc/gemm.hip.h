@@ -12,6 +12,7 @@
 //                   the PPO losses and their gradients.
 // Mirrors mineral/nets/mlp.py:50-77 (Linear -> LayerNorm -> SiLU) and torch autograd's backward of it.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -218,7 +219,9 @@ struct GemmCfg {
 // registers per lane (the LayerNorm / heads epilogues need the larger budget)
 constexpr int gemm_min_waves(int bm, int bn, int epi) { return (epi == EPI_SLAB && bm * bn / 256 <= 64) ? 3 : 2; }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF>
+// MM 1: the main loop multiplies on the bf16 matrix cores from exact three-term splits of the fp32 operands (fp32
+// accuracy, see split_main_loop below); built for forward tiles with both operands k-contiguous and K a multiple of 16.
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF, int MM = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
   constexpr int TM = C::TM, TN = C::TN, SA = C::SA, SB = C::SB;
@@ -230,7 +233,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   static_assert(NT % (C::CA / 4) == 0 && NT % (C::CB / 4) == 0, "each thread stages one fixed column chunk");
   static_assert(NT == 256 || EPI == EPI_LNFWD || EPI == EPI_BIASFWD, "8-wave blocks are built for the forward kernels");
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
-  constexpr int LDS_ALL = (NBUF * C::LDS_TILES > C::LDS_EPI) ? NBUF * C::LDS_TILES : C::LDS_EPI;
+  static_assert(MM == 0 || (LA == LAY_K && LB == LAY_K && BK == 16 && NT == 256 && EPI != EPI_SLAB), "split main loop: forward tiles, 16 k per step");
+  // split main loop: per stage three bf16 planes of [BM + BN rows][16 k] (32 B per row), two stages
+  constexpr int LDS_MAIN = MM ? 2 * 3 * (BM + BN) * 8 : NBUF * C::LDS_TILES;
+  constexpr int LDS_ALL = (LDS_MAIN > C::LDS_EPI) ? LDS_MAIN : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
 
   MRL_KT(1000);
@@ -456,7 +462,126 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   };
 
   constexpr int NG = BK / 8;   // k sub-steps per tile
-  if constexpr (NBUF == 1) {
+  if constexpr (MM == 1) {
+    // Every fp32 operand element is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by
+    // truncation) and each product is accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms
+    // are below 2^-24 of |a*b|.  Planes live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on
+    // every other group of 8 rows (a quarter-wave's 16-byte fragment reads then cover all banks).  Per step: the MFMAs of
+    // step st from stage st & 1, then the operands of step st+1 (in registers since two steps) are split into the other
+    // stage and the loads of step st+3 issued; one barrier per step.
+    using sp_u32x2 = unsigned int __attribute__((ext_vector_type(2)));
+    using sp_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+    constexpr int ROWS = BM + BN, SPLANE = ROWS * 32, SSTAGE = 3 * SPLANE;
+    constexpr int A_CH = BM * 4 / NT, B_CH = BN * 4 / NT;           // 16-byte chunks per thread and step
+    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "whole chunks per thread");
+    char* sl = reinterpret_cast<char*>(lds);
+    const int K = kend;                                              // kbeg == 0 in the forward kernels
+    const int nsteps = K / 16;
+    const int ca = tid & 3, row0 = tid >> 2;                         // chunk ca of rows row0 + 64 i
+    auto r_off = [](int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) * 16); };
+    f32x4 sa[2][A_CH], sb[2][B_CH], spv0[2], spv1[2];               // [register set = step parity]
+    auto sp_load = [&](int st, auto SET) {
+      constexpr int S = decltype(SET)::value;
+      const int k0 = min(st * 16, K - 16) + 4 * ca;                  // steps past the end re-read the last one; never multiplied
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) sa[S][i] = *reinterpret_cast<const f32x4*>(Ag + (int64_t)min(m0 + row0 + 64 * i, p.M - 1) * p.lda + k0);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) sb[S][i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(n0 + row0 + 64 * i, Nv - 1) * p.ldb + k0);
+      if constexpr (PRO_ON_A && PRO_VEC) {
+        spv0[S] = *reinterpret_cast<const f32x4*>(pro0 + k0);
+        spv1[S] = *reinterpret_cast<const f32x4*>(pro1 + k0);
+      }
+    };
+    auto sp_split = [&](const f32x4 x, char* q) {
+      unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned xb = __float_as_uint(x[e]);
+        hb[e] = xb & 0xffff0000u;
+        const float r1 = x[e] - __uint_as_float(hb[e]);
+        mb[e] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mb[e]);
+        lb[e] = __float_as_uint(r2);                                 // at most 8 significant bits are left: its upper half is exact
+      }
+      sp_u32x2 w;
+      w[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+      *reinterpret_cast<sp_u32x2*>(q) = w;
+      w[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+      *reinterpret_cast<sp_u32x2*>(q + SPLANE) = w;
+      w[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+      *reinterpret_cast<sp_u32x2*>(q + 2 * SPLANE) = w;
+    };
+    auto sp_stage = [&](auto SET) {
+      constexpr int S = decltype(SET)::value;
+      char* buf = sl + S * SSTAGE;
+      if constexpr (PRO_ON_A && PRO_VEC) { pv0 = spv0[S]; pv1 = spv1[S]; }
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = sa[S][i];
+        if constexpr (PRO_ON_A) v = transform(v);
+        sp_split(v, buf + r_off(row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = n0 + row0 + 64 * i < Nv;                    // weight rows past the valid outputs contribute zeros
+        sp_split(ok ? sb[S][i] : zero, buf + r_off(BM + row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
+      }
+    };
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa_off[i] = r_off(wm * TM * 32 + i * 32 + l32, h);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb_off[i] = r_off(BM + wn * TN * 32 + i * 32 + l32, h);
+    auto sp_mfmas = [&](auto SET) {
+      constexpr int S = decltype(SET)::value;
+      const char* cur = sl + S * SSTAGE;
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // (a plane, b plane) of the six terms, smallest first
+      sp_bf16x8 fa[TM][3], fb[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i][pl] = *reinterpret_cast<const sp_bf16x8*>(cur + pl * SPLANE + fa_off[i]);
+        fb[0][pl] = *reinterpret_cast<const sp_bf16x8*>(cur + pl * SPLANE + fb_off[0]);
+      }
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        if (in + 1 < TN) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fb[(in + 1) & 1][pl] = *reinterpret_cast<const sp_bf16x8*>(cur + pl * SPLANE + fb_off[in + 1]);
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+            if constexpr (EPI == EPI_LNFWD || EPI == EPI_BIASFWD)   // transposed product, as in the fp32 loop
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[in & 1][TB[term]], fa[im][TA[term]], acc[im][in], 0, 0, 0);
+            else
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[im][TA[term]], fb[in & 1][TB[term]], acc[im][in], 0, 0, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto sp_step = [&](int st, auto PAR) {
+      constexpr int P = decltype(PAR)::value;
+      using Q = std::integral_constant<int, P ^ 1>;
+      sp_mfmas(PAR);
+      sp_stage(Q{});
+      sp_load(st + 3, Q{});
+      __syncthreads();
+    };
+    sp_load(0, I0{});
+    sp_load(1, I1{});
+    sp_stage(I0{});
+    sp_load(2, I0{});
+    __syncthreads();
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+      sp_step(st, I0{});
+      sp_step(st + 1, I1{});
+    }
+    if (st < nsteps) sp_step(st, I0{});
+  } else if constexpr (NBUF == 1) {
     f32x4 af[TM], bf[TN];
     if (kbeg < kend) load_tiles(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {

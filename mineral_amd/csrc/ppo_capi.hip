@@ -294,10 +294,11 @@ extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
 }
 #endif
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2>
+template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2, int MM = 0>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident = 0) {
   using Cfg = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
-  constexpr int static_lds = 4 * ((NBUF * Cfg::LDS_TILES > Cfg::LDS_EPI) ? NBUF * Cfg::LDS_TILES : Cfg::LDS_EPI);
+  constexpr int main_lds = MM ? 2 * 3 * (BM + BN) * 8 : NBUF * Cfg::LDS_TILES;
+  constexpr int static_lds = 4 * ((main_lds > Cfg::LDS_EPI) ? main_lds : Cfg::LDS_EPI);
   unsigned dyn_lds = 0;
   if (resident > 0) {
     const int per_block = (MRL_LDS_PER_CU / resident) & ~1023;
@@ -305,7 +306,8 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
   }
   static int cls = [] {
     char nm[96];
-    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
+    if (MM) snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM);
+    else snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -327,9 +329,9 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
     pt.ktrace = (want && strcmp(want, nm) == 0 && (!want_m || atoi(want_m) == p.M)) ? 1 + (want_z ? atoi(want_z) : 0) : 0;
     pt.ablate = (pt.ktrace && abl) ? atoi(abl) : 0;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(64 * WGM * WGN), dyn_lds, s, pt);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM>), grid, dim3(64 * WGM * WGN), dyn_lds, s, pt);
 #else
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF>), grid, dim3(64 * WGM * WGN), dyn_lds, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM>), grid, dim3(64 * WGM * WGN), dyn_lds, s, p);
 #endif
   if (timed) {
     (void)hipEventRecord(e1, s);
@@ -445,6 +447,18 @@ static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers
   else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
+// Hidden LayerNorm layers of 128 or 256 outputs on batches above MRL_SMALL_M rows run the split-bf16 main loop of gemm_kernel
+// (fp32 accuracy on the bf16 matrix cores); false = not eligible, the caller launches the fp32 tile.
+template <int PRO>
+static bool launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s) {
+  if (p.M <= MRL_SMALL_M || p.K % 16 || p.K < 16) return false;
+  const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
+  if (u == 256) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
+  else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
+  else return false;
+  return true;
+}
+
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
 static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
                               const float* x, int64_t rows, const float* obs_mean, const float* obs_std, float lo, float hi,
@@ -472,8 +486,11 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_ELU, p, towers, s);
       else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NORM, p, towers, s);
       else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NONE, p, towers, s);
-    } else if (l > 0 && net->tower_kind == TOWER_LAYERNORM_ELU) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNELU, p, towers, s);
-    else if (l > 0) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    } else if (l > 0 && net->tower_kind == TOWER_LAYERNORM_ELU) {
+      if (!launch_lnfwd_split<PRO_LNELU>(u, p, towers, s)) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNELU, p, towers, s);
+    } else if (l > 0) {
+      if (!launch_lnfwd_split<PRO_LNSILU>(u, p, towers, s)) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    }
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
     else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
   }
