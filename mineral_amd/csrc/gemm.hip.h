@@ -67,6 +67,10 @@ struct GemmP {
   int M, N, K;                 // GEMM sizes (M rows, N cols, K reduction); all loads are guarded by these
   int Nt[2], Kt[2];            // per-tower valid N / K (the heads differ: 2*act_dim vs 1); 0 = use N / K
   int tw0;                     // role of blockIdx.z == 0: 0 actor, 1 critic (critic-only launches)
+  // weights pre-split into three bf16 planes (same row-major element order as B; plane q of tower z starts at
+  // Bpl[z] + q * pl_stride); read instead of B by dgrad_split_kernel<true>
+  const unsigned short* Bpl[2];
+  int64_t pl_stride;
   const float* pro0[2];        // PRO_NORM: mean[f]   PRO_LNSILU / PRO_LNELU: gamma[f]
   const float* pro1[2];        // PRO_NORM: std[f]    PRO_LNSILU / PRO_LNELU: beta[f]
   float clamp_lo, clamp_hi;
@@ -220,7 +224,9 @@ struct GemmCfg {
 constexpr int gemm_min_waves(int bm, int bn, int epi) { return (epi == EPI_SLAB && bm * bn / 256 <= 64) ? 3 : 2; }
 
 // MM 1: the main loop multiplies on the bf16 matrix cores from exact three-term splits of the fp32 operands (fp32
-// accuracy, see split_main_loop below); built for forward tiles with both operands k-contiguous and K a multiple of 16.
+// accuracy, see the MM branch of the main loop); built for forward tiles with both operands k-contiguous and K a multiple
+// of 16.  (Reading the weights from planes split beforehand, as dgrad_split_kernel<true> does, was measured here too: 125
+// against 120 us for the 512 -> 256 layer, so the forward splits both operands itself.)
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF, int MM = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void gemm_kernel(const GemmP p) {
   using C = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
@@ -479,17 +485,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     const int nsteps = K / 16;
     const int ca = tid & 3, row0 = tid >> 2;                         // chunk ca of rows row0 + 64 i
     auto r_off = [](int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) * 16); };
-    f32x4 sa[2][A_CH], sb[2][B_CH], spv0[2], spv1[2];               // [register set = step parity]
+    // A (activations, from HBM) is loaded three steps ahead into alternating register sets; the weights and the prologue
+    // vectors (L2-resident, every block reads the same) one step ahead into a single set
+    f32x4 sa[2][A_CH], sb[B_CH], spv0, spv1;
     auto sp_load = [&](int st, auto SET) {
       constexpr int S = decltype(SET)::value;
       const int k0 = min(st * 16, K - 16) + 4 * ca;                  // steps past the end re-read the last one; never multiplied
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) sa[S][i] = *reinterpret_cast<const f32x4*>(Ag + (int64_t)min(m0 + row0 + 64 * i, p.M - 1) * p.lda + k0);
+    };
+    auto sp_load_w = [&](int st) {
+      const int k0 = min(st * 16, K - 16) + 4 * ca;
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i) sb[S][i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(n0 + row0 + 64 * i, Nv - 1) * p.ldb + k0);
+      for (int i = 0; i < B_CH; ++i) sb[i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(n0 + row0 + 64 * i, Nv - 1) * p.ldb + k0);
       if constexpr (PRO_ON_A && PRO_VEC) {
-        spv0[S] = *reinterpret_cast<const f32x4*>(pro0 + k0);
-        spv1[S] = *reinterpret_cast<const f32x4*>(pro1 + k0);
+        spv0 = *reinterpret_cast<const f32x4*>(pro0 + k0);
+        spv1 = *reinterpret_cast<const f32x4*>(pro1 + k0);
       }
     };
     auto sp_split = [&](const f32x4 x, char* q) {
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     auto sp_stage = [&](auto SET) {
       constexpr int S = decltype(SET)::value;
       char* buf = sl + S * SSTAGE;
-      if constexpr (PRO_ON_A && PRO_VEC) { pv0 = spv0[S]; pv1 = spv1[S]; }
+      if constexpr (PRO_ON_A && PRO_VEC) { pv0 = spv0; pv1 = spv1; }
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
         f32x4 v = sa[S][i];
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       for (int i = 0; i < B_CH; ++i) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const bool ok = n0 + row0 + 64 * i < Nv;                    // weight rows past the valid outputs contribute zeros
-        sp_split(ok ? sb[S][i] : zero, buf + r_off(BM + row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
+        sp_split(ok ? sb[i] : zero, buf + r_off(BM + row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
       }
     };
     int fa_off[TM], fb_off[TN];
@@ -568,12 +579,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       sp_mfmas(PAR);
       sp_stage(Q{});
       sp_load(st + 3, Q{});
+      sp_load_w(st + 2);
       __syncthreads();
     };
     sp_load(0, I0{});
     sp_load(1, I1{});
+    sp_load_w(0);
     sp_stage(I0{});
     sp_load(2, I0{});
+    sp_load_w(1);
     __syncthreads();
     int st = 0;
     for (; st + 1 < nsteps; st += 2) {

@@ -169,6 +169,8 @@ struct Workspace {
   int64_t metric_part;   // doubles, 8-byte aligned
   int64_t headb_part;    // [rows/128][2][32] column sums of the head seeds (bias gradients)
   int64_t small;         // misc: obs mean/std f32 (2*obs_dim), partial sums
+  int64_t wplanes;       // the parameter vector split into three bf16 planes (wplane_stride elements each), refreshed by the launches that read it
+  int64_t wplane_stride;
   int64_t total;
   WgradPlan wp[MRL_MAX_LAYERS], wph;
   int rowblocks[MRL_MAX_LAYERS];
@@ -200,6 +202,8 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   w->metric_part = o; o = align64(o + 2 * cdiv(rows, 128) * 2 * MRL_NMETRIC + 64);
   w->headb_part = o; o = align64(o + cdiv(rows, 128) * 64);
   w->small = o; o = align64(o + 4096 + 2 * (int64_t)net->obs_dim + 16 * cdiv(rows, 64));
+  w->wplane_stride = align64(L.total);
+  w->wplanes = o; o = align64(o + (3 * w->wplane_stride + 1) / 2);
   w->total = o;
 }
 
@@ -306,8 +310,7 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
   }
   static int cls = [] {
     char nm[96];
-    if (MM) snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM);
-    else snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF);
+    snprintf(nm, sizeof(nm), "mrl::gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -410,6 +413,8 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
 // input gradients of the wide layers (N a multiple of 128, K of 16) through dgrad_split_kernel; same grid as the fp32 launch
 static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
   static int cls = prof_register("mrl::dgrad_split_kernel");
+  bool planes = p.Bpl[0] != nullptr;                  // 16-byte plane chunks need weight matrices that start on a multiple of 8 elements
+  for (unsigned z = 0; z < grid.z; ++z) planes = planes && p.Bpl[z] && ((uintptr_t)p.Bpl[z] % 16 == 0);
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
@@ -417,7 +422,8 @@ static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL(dgrad_split_kernel, grid, dim3(256), 0, s, p);
+  if (planes) hipLaunchKernelGGL(dgrad_split_kernel<true>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(dgrad_split_kernel<false>, grid, dim3(256), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -447,16 +453,36 @@ static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers
   else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
+// The whole parameter vector as three bf16 planes with x = h + m + l exactly (the split of split_bf16.hip.h), element for
+// element: dgrad_split_kernel<true> reads its weight tiles from the planes instead of splitting them in every block.
+__global__ void split_params_kernel(const float* __restrict__ params, int64_t n, unsigned short* __restrict__ planes, int64_t stride) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = params[i];
+  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  planes[i] = (unsigned short)(hb >> 16);
+  planes[stride + i] = (unsigned short)(mb >> 16);
+  planes[2 * stride + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+static unsigned short* launch_split_params(const ParamLayout& L, const Workspace& W, float* ws, const float* params, hipStream_t s) {
+  unsigned short* planes = reinterpret_cast<unsigned short*>(ws + W.wplanes);
+  hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)cdiv(L.total, 256)), dim3(256), 0, s, params, L.total, planes, W.wplane_stride);
+  return planes;
+}
+
 // Hidden LayerNorm layers of 128 or 256 outputs on batches above MRL_SMALL_M rows run the split-bf16 main loop of gemm_kernel
 // (fp32 accuracy on the bf16 matrix cores); false = not eligible, the caller launches the fp32 tile.
+static bool lnfwd_split_eligible(int u, int64_t rows, int in) { return rows > MRL_SMALL_M && in % 16 == 0 && in >= 16 && (u == 256 || u == 128); }
+
 template <int PRO>
-static bool launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s) {
-  if (p.M <= MRL_SMALL_M || p.K % 16 || p.K < 16) return false;
+static void launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s) {
   const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
   if (u == 256) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
-  else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
-  else return false;
-  return true;
+  else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
 }
 
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
@@ -487,9 +513,11 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NORM, p, towers, s);
       else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_BIASFWD, PRO_NONE, p, towers, s);
     } else if (l > 0 && net->tower_kind == TOWER_LAYERNORM_ELU) {
-      if (!launch_lnfwd_split<PRO_LNELU>(u, p, towers, s)) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNELU, p, towers, s);
+      if (lnfwd_split_eligible(u, rows, in)) launch_lnfwd_split<PRO_LNELU>(u, p, towers, s);
+      else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNELU, p, towers, s);
     } else if (l > 0) {
-      if (!launch_lnfwd_split<PRO_LNSILU>(u, p, towers, s)) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+      if (lnfwd_split_eligible(u, rows, in)) launch_lnfwd_split<PRO_LNSILU>(u, p, towers, s);
+      else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
     }
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
     else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
@@ -1328,11 +1356,16 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
                               float* const* input_grad, hipStream_t s) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  const unsigned short* planes = nullptr;             // refreshed here: the caller may have changed the parameters since the forward
+  if (L.has_norm && mb > MRL_SMALL_M)
+    for (int l = 0; l < last && !planes; ++l)
+      if (ln_bwd_streamed(net->units[l]) && net->units[l + 1] % 16 == 0) planes = launch_split_params(L, W, ws, params, s);
   // ---- dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) --------------------------
   for (int l = last; l >= 0; --l) {
     GemmP p;
     memset(&p, 0, sizeof(p));
     const int u = net->units[l];
+    p.pl_stride = W.wplane_stride;
     for (int k = 0; k < towers; ++k) {
       const int tw = tw0 + k;
       if (l == last) {
@@ -1342,6 +1375,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       } else {
         p.A[k] = ws + W.dz[tw][l + 1];
         p.B[k] = params + L.W[tw][l + 1];
+        p.Bpl[k] = planes ? planes + L.W[tw][l + 1] : nullptr;
         p.Kt[k] = net->units[l + 1];
       }
       p.Nt[k] = u;

@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
 // Input gradient of a wide layer: out[m][n] = sum_k A[m][k] B[k][n] with A = dZ of the layer above ([rows][K], K along the
 // row) and B = that layer's weights ([K][N]).  K must be a multiple of 16; rows past M are computed from clamped loads and
 // not stored.
+// WPL: the weights come from planes split beforehand (GemmP::Bpl) and go to LDS as they are.
+template <bool WPL>
 __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
   constexpr int APLANE = BM * 32;          // [128 rows][16 k] bf16, 32 B per row; the two 16-byte halves of a row swap places
@@ -266,7 +268,11 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   const int ca = t & 3, rowa = t >> 2;
   const int c = t & 31, kr = t >> 5;
   auto a_off = [](int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) * 16); };
-  f32x4 ra[2][2], rb[2][2];                             // [register set = step parity][row]
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[2][2], rb[2][WPL ? 1 : 2];                   // [register set = step parity][row]
+  u32x4 rw[2][WPL ? 3 : 1];                             // WPL: one 16-byte chunk (8 columns) of row t >> 4 per plane
+  const unsigned short* Wpl = p.Bpl[tw];
+  const int wrow = t >> 4, wch = t & 15;
   auto gload = [&](int st, auto SET) {
     constexpr int S = decltype(SET)::value;
     const int k0 = min(st * BK, K - BK);                // steps past the end re-read the last one; they are never multiplied
@@ -274,7 +280,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
     for (int i = 0; i < 2; ++i) {
       const int64_t row = min(m0 + rowa + 64 * i, p.M - 1);
       ra[S][i] = *reinterpret_cast<const f32x4*>(Ag + row * p.lda + k0 + 4 * ca);
-      rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)(k0 + kr + 8 * i) * p.ldb + n0 + 4 * c);
+      if constexpr (!WPL) rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)(k0 + kr + 8 * i) * p.ldb + n0 + 4 * c);
+    }
+    if constexpr (WPL) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        rw[S][pl] = *reinterpret_cast<const u32x4*>(Wpl + pl * p.pl_stride + (int64_t)(k0 + wrow) * p.ldb + n0 + 8 * wch);
     }
   };
   auto stage = [&](auto SET) {
@@ -288,11 +299,17 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
       *reinterpret_cast<u32x2*>(qa) = h;
       *reinterpret_cast<u32x2*>(qa + APLANE) = m;
       *reinterpret_cast<u32x2*>(qa + 2 * APLANE) = l;
-      char* qb = buf + AOPER + (kr + 8 * i) * ROWB + c * 8;
-      split4(rb[S][i], h, m, l);
-      *reinterpret_cast<u32x2*>(qb) = h;
-      *reinterpret_cast<u32x2*>(qb + PLANE) = m;
-      *reinterpret_cast<u32x2*>(qb + 2 * PLANE) = l;
+      if constexpr (!WPL) {
+        char* qb = buf + AOPER + (kr + 8 * i) * ROWB + c * 8;
+        split4(rb[S][i], h, m, l);
+        *reinterpret_cast<u32x2*>(qb) = h;
+        *reinterpret_cast<u32x2*>(qb + PLANE) = m;
+        *reinterpret_cast<u32x2*>(qb + 2 * PLANE) = l;
+      }
+    }
+    if constexpr (WPL) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(buf + AOPER + pl * PLANE + wrow * ROWB + wch * 16) = rw[S][pl];
     }
   };
 
