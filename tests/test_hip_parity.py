@@ -54,6 +54,7 @@ NETS = {
     'elu_head': dict(obs=64, act=12, units=[512, 128], norm=None, actf='ELU', fixed=False),
     'ln_fixed': dict(obs=64, act=12, units=[128, 64], fixed=True),
     'obs128': dict(obs=128, act=12, units=[128, 128]),
+    'odd_heads': dict(obs=64, act=3, units=[256, 128]),     # 6-row heads: the tensors behind them start on odd offsets
 }
 
 
@@ -261,6 +262,7 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('full', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
+    ('odd_heads', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
 ])
 def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
     spec = NETS[net]
