@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-value
 SRC = mineral_amd/csrc/ppo_capi.hip mineral_amd/csrc/replay.hip
-HDR = mineral_amd/csrc/gemm.hip.h mineral_amd/csrc/sac_capi.hip.inc mineral_amd/csrc/shac_capi.hip.inc include/mineral_ppo.h include/mineral_replay.h include/mineral_sac.h include/mineral_shac.h
+HDR = mineral_amd/csrc/gemm.hip.h mineral_amd/csrc/split_bf16.hip.h mineral_amd/csrc/sac_capi.hip.inc mineral_amd/csrc/shac_capi.hip.inc include/mineral_ppo.h include/mineral_replay.h include/mineral_sac.h include/mineral_shac.h
 LIB = mineral_amd/libmineral_ppo.so
 
 all: $(LIB)
@@ -22,6 +22,11 @@ ktrace: $(SRC) $(HDR)
 ktrace-ablate: $(SRC) $(HDR)
 	mkdir -p tools/bin && $(HIPCC) $(HIPFLAGS) -DMRL_KTRACE -DMRL_KTRACE_ABLATE $(SRC) -o tools/bin/libmineral_ppo_ktrace.so
 
+# stand-alone measurement programs (run on the GPU box: tools/bin travels with the tree)
+PROBES = mfma_peak_probe mfma_overlap_probe placement_probe bf16x3_split_probe
+probes:
+	mkdir -p tools/bin && for p in $(PROBES); do $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops tools/$$p.hip -o tools/bin/$$p || exit 1; done
+
 clean:
 	rm -f $(LIB)
-.PHONY: all resources ktrace ktrace-ablate clean
+.PHONY: all resources ktrace ktrace-ablate probes clean

@@ -15,6 +15,10 @@
  *     mineral/agents/ppo/experience.py:7-14 — and minibatch i is the contiguous row range [i*mb, (i+1)*mb)
  *     (experience.py:61-64).  Per-step scalars are staged TIME-MAJOR ([T][N]) during collection and converted by
  *     mrl_gae_finish.
+ *   - arithmetic: fp32 operands, fp32 accumulation, fp32 results everywhere.  On batches above 8,192 rows the GEMMs of the
+ *     hidden layers multiply on the bf16 matrix cores from exact three-term splits of their fp32 operands (six bf16
+ *     products per fp32 product, accumulated in fp32); the error against an exact sum is below that of an fp32 fma chain,
+ *     and results differ from the fp32-MFMA path only by summation order and that rounding.
  */
 #ifndef MINERAL_PPO_H
 #define MINERAL_PPO_H
