@@ -380,18 +380,19 @@ static inline unsigned slab_grid(int n_groups, int group_size) { return (unsigne
 constexpr int64_t MRL_WGRAD_SPLIT_MIN_ROWS = 8192;   // below this the launch is latency-bound and the fp32 kernel's shorter prologue wins
 
 static bool wgrad_split_eligible(const GemmP& p, const WgradPlan& w, int towers) {
-  if (w.bm != 128 || w.bn != 128 || p.M % 128 || p.N % 128 || p.K < MRL_WGRAD_SPLIT_MIN_ROWS) return false;
+  if (w.bm != 128 || p.M % 128 || p.K < MRL_WGRAD_SPLIT_MIN_ROWS) return false;
+  if (!(w.bn == 128 && p.N % 128 == 0) && !(w.bn == 64 && p.N == 64)) return false;
   if (p.lda % 4 || p.ldb % 4) return false;
   for (int z = 0; z < towers; ++z)
     if (p.Nt[z] && p.Nt[z] != p.N) return false;
   return true;
 }
 
-template <int PRO>
+template <int PRO, int BNT>
 static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
   static int cls = [] {
     char nm[96];
-    snprintf(nm, sizeof(nm), "mrl::wgrad_split_kernel<%d>", PRO);
+    snprintf(nm, sizeof(nm), "mrl::wgrad_split_kernel<%d, %d>", PRO, BNT);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -401,7 +402,7 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((wgrad_split_kernel<PRO>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((wgrad_split_kernel<PRO, BNT>), grid, dim3(256), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -435,8 +436,10 @@ static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
 template <int PRO>
 static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
   dim3 grid(slab_grid(w.nsplit, w.tiles_m * w.tiles_n), 1, towers);
-  if (wgrad_split_eligible(p, w, towers))
-    launch_wgrad_split<PRO>(p, grid, s);
+  if (wgrad_split_eligible(p, w, towers)) {
+    if (w.bn == 128) launch_wgrad_split<PRO, 128>(p, grid, s);
+    else launch_wgrad_split<PRO, 64>(p, grid, s);
+  }
   else if (w.bm == 32)
     launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);
   else if (w.bn == 64)

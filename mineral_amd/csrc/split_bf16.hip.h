@@ -66,10 +66,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base) {
 }
 }  // namespace wsplit
 
-template <int PRO>
+// BNT: output columns per tile, 128 (2 x 2 waves of 64 x 64) or 64 (2 x 2 waves of 64 x 32, for a first layer on 64 observations;
+// the B planes then take a 192-byte row pitch, with which four consecutive rows still cover all banks).
+template <int PRO, int BNT>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  static_assert(BNT == 128 || BNT == 64, "column tiles of 128 or 64");
+  constexpr int TN = BNT / 64;                          // 32-column MFMA tiles per wave
+  constexpr int BROW = BNT == 128 ? ROWB : 192;         // row pitch of a B plane
+  constexpr int BPLANE = BK * BROW;
+  constexpr int WSTAGE = OPER + 3 * BPLANE;             // A planes, then B planes
+  constexpr int B_CPR = BNT / 4;                        // 4-float chunks per B row
+  constexpr int B_F4 = BK * B_CPR / 256;                // B chunks per thread and step: 2 or 1
+  __shared__ __attribute__((aligned(16))) char lds[2 * WSTAGE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tw = blockIdx.z;
@@ -78,20 +87,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
   const int lin = blockIdx.x, tq = lin >> 3, j = tq % gsz;
   const int split = (tq / gsz) * 8 + (lin & 7);
   if (split >= p.n_groups) return;                     // padding blocks of the last octet of splits (whole blocks leave)
-  const int m0 = (j % p.m_tiles) * BM, n0 = (j / p.m_tiles) * BN;
+  const int m0 = (j % p.m_tiles) * BM, n0 = (j / p.m_tiles) * BNT;
   const int kfull = p.Kt[tw] ? p.Kt[tw] : p.K;
   const int kbeg = split * p.ksplit, kend = min(kfull, kbeg + p.ksplit);
   const int nsteps = (kend - kbeg + BK - 1) / BK;
   const float* __restrict__ Ag = p.A[tw];
   const float* __restrict__ Bg = p.B[tw];
 
-  // staging map: chunk c (4 columns) of rows (t >> 5) and (t >> 5) + 8 of each 16-row step
+  // staging map: A chunk c (4 columns) of rows (t >> 5) and (t >> 5) + 8 of each 16-row step; B chunk cb of rows
+  // krb + (256 / B_CPR) i
   const int c = t & 31, kr = t >> 5;
+  const int cb = t % B_CPR, krb = t / B_CPR;
   constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU || PRO == PRO_LNELU;
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};
   if constexpr (PRO_VEC) {                              // the feature index of a B column does not change along the reduction
-    pv0 = *reinterpret_cast<const f32x4*>(p.pro0[tw] + n0 + 4 * c);
-    pv1 = *reinterpret_cast<const f32x4*>(p.pro1[tw] + n0 + 4 * c);
+    pv0 = *reinterpret_cast<const f32x4*>(p.pro0[tw] + n0 + 4 * cb);
+    pv1 = *reinterpret_cast<const f32x4*>(p.pro1[tw] + n0 + 4 * cb);
   }
   auto transform = [&](f32x4 v) {
     f32x4 o = v;
@@ -117,64 +128,78 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
     return o;
   };
 
-  f32x4 ra[2][2], rb[2][2];                             // [register set = step parity][row]
+  f32x4 ra[2][2], rb[2][B_F4];                          // [register set = step parity][row]
   auto gload = [&](int st, auto SET) {
     constexpr int S = decltype(SET)::value;
-    const int k = kbeg + st * BK + kr;
+    const int k = kbeg + st * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int64_t kk = min(k + 8 * i, kfull - 1);     // rows past the end are loaded clamped and zeroed when staged
+      const int64_t kk = min(k + kr + 8 * i, kfull - 1);   // rows past the end are loaded clamped and zeroed when staged
       ra[S][i] = *reinterpret_cast<const f32x4*>(Ag + kk * p.lda + m0 + 4 * c);
-      rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + kk * p.ldb + n0 + 4 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int64_t kk = min(k + krb + (256 / B_CPR) * i, kfull - 1);
+      rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + kk * p.ldb + n0 + 4 * cb);
     }
   };
   auto stage = [&](int st, auto SET) {
     constexpr int S = decltype(SET)::value;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    char* buf = lds + S * STAGE;
-    const int k = kbeg + st * BK + kr;
+    char* buf = lds + S * WSTAGE;
+    const int k = kbeg + st * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = k + 8 * i < kend;
       u32x2 h, m, l;
       char* q = buf + (kr + 8 * i) * ROWB + c * 8;
-      split4(ok ? ra[S][i] : zero, h, m, l);
+      split4(k + kr + 8 * i < kend ? ra[S][i] : zero, h, m, l);
       *reinterpret_cast<u32x2*>(q) = h;
       *reinterpret_cast<u32x2*>(q + PLANE) = m;
       *reinterpret_cast<u32x2*>(q + 2 * PLANE) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      u32x2 h, m, l;
+      const int row = krb + (256 / B_CPR) * i;
+      char* q = buf + OPER + row * BROW + cb * 8;
       f32x4 v = rb[S][i];
       if constexpr (PRO != PRO_NONE) v = transform(v);
-      split4(ok ? v : zero, h, m, l);
-      *reinterpret_cast<u32x2*>(q + OPER) = h;
-      *reinterpret_cast<u32x2*>(q + OPER + PLANE) = m;
-      *reinterpret_cast<u32x2*>(q + OPER + 2 * PLANE) = l;
+      split4(k + row < kend ? v : zero, h, m, l);
+      *reinterpret_cast<u32x2*>(q) = h;
+      *reinterpret_cast<u32x2*>(q + BPLANE) = m;
+      *reinterpret_cast<u32x2*>(q + 2 * BPLANE) = l;
     }
   };
 
   // fragment map of v_mfma_f32_32x32x16_bf16 through transposed reads: 16-lane group g takes columns 16 (g & 1) .. +15 and
   // rows 8 (g >> 1) .. +7 of the step; lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3
   const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int frag_off = (8 * (g >> 1) + q4) * ROWB + (16 * (g & 1) + 4 * p4) * 2;
-  const int fa = frag_off + (wm * 64) * 2;
-  const int fb = OPER + frag_off + (wn * 64) * 2;
-  bf16x8 fra[2][2][3], frb[2][2][3];                   // [fragment set = step parity][tile][plane]
+  const int fa = (8 * (g >> 1) + q4) * ROWB + (16 * (g & 1) + 4 * p4) * 2 + (wm * 64) * 2;
+  const int fb = OPER + (8 * (g >> 1) + q4) * BROW + (16 * (g & 1) + 4 * p4) * 2 + (wn * 32 * TN) * 2;
+  auto tr_frag_b = [](const char* base) {               // tr_frag with the B row pitch
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * BROW));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  bf16x8 fra[2][2][3], frb[2][TN][3];                  // [fragment set = step parity][tile][plane]
   auto frags = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
-    const char* cur = lds + S * STAGE;
+    const char* cur = lds + S * WSTAGE;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fra[S][i][pl] = tr_frag(cur + fa + pl * PLANE + i * 64);
-        frb[S][i][pl] = tr_frag(cur + fb + pl * PLANE + i * 64);
-      }
+      for (int i = 0; i < 2; ++i) fra[S][i][pl] = tr_frag(cur + fa + pl * PLANE + i * 64);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) frb[S][i][pl] = tr_frag_b(cur + fb + pl * BPLANE + i * 64);
+    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
   auto mfmas = [&](auto SET) {
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < TN; ++jn)
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[S][i][TA[term]], frb[S][jn][TB[term]], acc[i][jn], 0, 0, 0);
   };
 
@@ -231,11 +256,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + col] = acc[i][jn][r];
+        out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col] = acc[i][jn][r];
       }
 }
 
