@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
   static_assert(MM == 0 || (LA == LAY_K && LB == LAY_K && BK == 16 && NT == 256 && EPI != EPI_SLAB), "split main loop: forward tiles, 16 k per step");
   // split main loop: per stage three bf16 planes of [BM + BN rows][16 k] (32 B per row), two stages
-  constexpr int LDS_MAIN = MM ? 2 * 3 * (BM + BN) * 8 : NBUF * C::LDS_TILES;
+  constexpr int LDS_MAIN = MM ? NBUF * 3 * (BM + BN) * 8 : NBUF * C::LDS_TILES;
   constexpr int LDS_ALL = (LDS_MAIN > C::LDS_EPI) ? LDS_MAIN : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
 
@@ -582,19 +582,32 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       sp_load_w(st + 2);
       __syncthreads();
     };
-    sp_load(0, I0{});
-    sp_load(1, I1{});
-    sp_load_w(0);
-    sp_stage(I0{});
-    sp_load(2, I0{});
-    sp_load_w(1);
-    __syncthreads();
-    int st = 0;
-    for (; st + 1 < nsteps; st += 2) {
-      sp_step(st, I0{});
-      sp_step(st + 1, I1{});
+    if constexpr (NBUF == 1) {                                       // short reductions (first layer): one stage, two barriers per step
+      sp_load(0, I0{});
+      sp_load_w(0);
+      for (int st = 0; st < nsteps; ++st) {
+        sp_stage(I0{});
+        __syncthreads();
+        sp_load(st + 1, I0{});
+        sp_load_w(st + 1);
+        sp_mfmas(I0{});
+        __syncthreads();
+      }
+    } else {
+      sp_load(0, I0{});
+      sp_load(1, I1{});
+      sp_load_w(0);
+      sp_stage(I0{});
+      sp_load(2, I0{});
+      sp_load_w(1);
+      __syncthreads();
+      int st = 0;
+      for (; st + 1 < nsteps; st += 2) {
+        sp_step(st, I0{});
+        sp_step(st + 1, I1{});
+      }
+      if (st < nsteps) sp_step(st, I0{});
     }
-    if (st < nsteps) sp_step(st, I0{});
   } else if constexpr (NBUF == 1) {
     f32x4 af[TM], bf[TN];
     if (kbeg < kend) load_tiles(kbeg);

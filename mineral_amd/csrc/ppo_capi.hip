@@ -301,7 +301,7 @@ extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2, int MM = 0>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident = 0) {
   using Cfg = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
-  constexpr int main_lds = MM ? 2 * 3 * (BM + BN) * 8 : NBUF * Cfg::LDS_TILES;
+  constexpr int main_lds = MM ? NBUF * 3 * (BM + BN) * 8 : NBUF * Cfg::LDS_TILES;
   constexpr int static_lds = 4 * ((main_lds > Cfg::LDS_EPI) ? main_lds : Cfg::LDS_EPI);
   unsigned dyn_lds = 0;
   if (resident > 0) {
@@ -521,6 +521,11 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
     } else if (l > 0) {
       if (lnfwd_split_eligible(u, rows, in)) launch_lnfwd_split<PRO_LNSILU>(u, p, towers, s);
       else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    }
+    else if (u == 512 && rows > MRL_SMALL_M && in % 16 == 0) {     // first layer of 512 outputs: split-bf16 main loop, single stage
+      const dim3 grid((unsigned)cdiv(p.M, 64), 1, towers);
+      if (obs_mean) launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NORM, 1, 1>(p, grid, s);
+      else launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NONE, 1, 1>(p, grid, s);
     }
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
     else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NONE, p, towers, s);
