@@ -221,3 +221,31 @@ def test_critic_rejects_unknown_activation():
     net = _hip.make_critic_net(12, 1, [64, 64])
     net.act_type = 7
     assert _hip.lib().mrl_critic_param_count(net) < 0
+
+
+@pytest.mark.parametrize('rows,O,units', [(9000, 128, [256, 128]), (20000, 64, [512, 256, 128])])
+def test_split_bf16_gemm_gradients_against_an_fp64_oracle(rows, O, units):
+    """Above 8,192 rows the forward, dgrad and wgrad GEMMs of these layers multiply exact three-term bf16 splits of their fp32
+    operands.  Yardstick: the same gradient computed by torch on the CPU in fp32; truth: the oracle in fp64.  The device result
+    has to be at least as close to the truth as the fp32 CPU result, and within 2e-6 of each tensor's largest entry."""
+    from mineral_amd.agents.diffrl import CriticLearner
+    c, pc = make_critic(O, units, 2, 31)
+    obs = synth.gaussianish((rows, O), 3)
+    tgt = synth.gaussianish((rows,), 4) * 2.0
+
+    def oracle_grads(dtype):
+        leaves = {k: v.to(dtype).clone().requires_grad_(True) for k, v in pc.items()}
+        loss = S.critic_loss(leaves, obs.to(dtype), tgt.to(dtype), units, 2)
+        return dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    learner = CriticLearner(c)
+    learner.compute_critic_loss({'obs': obs.to(DEV)}, tgt.to(DEV))
+    got = c.views_of(learner.grads)
+    err_dev = err_cpu = 0.0
+    for k, ref in g64.items():
+        scale = ref.abs().max().item()
+        err_dev = max(err_dev, (got[k].cpu().double() - ref).abs().max().item() / scale)
+        err_cpu = max(err_cpu, (g32[k].double() - ref).abs().max().item() / scale)
+    assert err_dev <= 2e-6, (err_dev, err_cpu)
+    assert err_dev <= err_cpu, (err_dev, err_cpu)
