@@ -17,7 +17,8 @@
 // loads run three steps ahead.  One barrier per step.
 //
 // Grids, split ranges and output layouts are those of the EPI_SLAB launches of gemm_kernel (group_mode 1 for wgrad, 0 for
-// dgrad), so plans, workspace and the slab reduction do not change.  Both need N to be a multiple of 128; wgrad also M.
+// dgrad), so plans, workspace and the slab reduction do not change.  dgrad needs N to be a multiple of 128 and K of 16; wgrad
+// needs M to be a multiple of 128 and N a multiple of 128 or equal to 64.
 #pragma once
 
 #include <type_traits>
@@ -33,7 +34,6 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int ROWB = 320;           // bytes per row of a plane: 128 bf16 + 64 B, so that four consecutive rows cover the 64 banks
 constexpr int PLANE = BK * ROWB;    // 5,120 B
 constexpr int OPER = 3 * PLANE;     // three planes per operand
-constexpr int STAGE = 2 * OPER;     // A and B of one step: 30,720 B; two stages
 
 // x (4 floats) -> three packed bf16 quadruples with x = h + m + l exactly
 __device__ __forceinline__ void split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
