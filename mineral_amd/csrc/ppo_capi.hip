@@ -388,11 +388,11 @@ static bool wgrad_split_eligible(const GemmP& p, const WgradPlan& w, int towers)
   return true;
 }
 
-template <int PRO, int BNT>
+template <int PRO, int BNT, int BMT>
 static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
   static int cls = [] {
     char nm[96];
-    snprintf(nm, sizeof(nm), "mrl::wgrad_split_kernel<%d, %d>", PRO, BNT);
+    snprintf(nm, sizeof(nm), "mrl::wgrad_split_kernel<%d, %d, %d>", PRO, BNT, BMT);
     return prof_register(nm);
   }();
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
@@ -402,7 +402,7 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((wgrad_split_kernel<PRO, BNT>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((wgrad_split_kernel<PRO, BNT, BMT>), grid, dim3(BMT * 2), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -437,8 +437,12 @@ template <int PRO>
 static void launch_wgrad_pro(const GemmP& p, const WgradPlan& w, int towers, hipStream_t s) {
   dim3 grid(slab_grid(w.nsplit, w.tiles_m * w.tiles_n), 1, towers);
   if (wgrad_split_eligible(p, w, towers)) {
-    if (w.bn == 128) launch_wgrad_split<PRO, 128>(p, grid, s);
-    else launch_wgrad_split<PRO, 64>(p, grid, s);
+    if (w.bn == 128 && w.tiles_m % 2 == 0) {           // 256-row tiles: same splits and slabs, half the tiles, 8 waves each
+      GemmP q = p;
+      q.m_tiles = w.tiles_m / 2;
+      launch_wgrad_split<PRO, 128, 256>(q, dim3(slab_grid(w.nsplit, q.m_tiles * w.tiles_n), 1, towers), s);
+    } else if (w.bn == 128) launch_wgrad_split<PRO, 128, 128>(p, grid, s);
+    else launch_wgrad_split<PRO, 64, 128>(p, grid, s);
   }
   else if (w.bm == 32)
     launch_gemm<32, 128, 16, 1, 4, LAY_R, LAY_R, EPI_SLAB, PRO>(p, grid, s, MRL_WGRAD_RESIDENT);

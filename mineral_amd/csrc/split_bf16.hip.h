@@ -66,18 +66,27 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base) {
 }
 }  // namespace wsplit
 
-// BNT: output columns per tile, 128 (2 x 2 waves of 64 x 64) or 64 (2 x 2 waves of 64 x 32, for a first layer on 64 observations;
-// the B planes then take a 192-byte row pitch, with which four consecutive rows still cover all banks).
-template <int PRO, int BNT>
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
+// BNT: output columns per tile, 128 (waves of 64 x 64) or 64 (waves of 64 x 32, for a first layer on 64 observations; the B
+// planes then take a 192-byte row pitch, with which four consecutive rows still cover all banks).
+// BMT: output rows per tile, 128 (2 x 2 waves) or 256 (4 x 2 waves, 512 threads: a tile of the layer input is then transformed
+// and split once for 256 output rows instead of once per 128, which is where most of this kernel's VALU work goes).
+template <int PRO, int BNT, int BMT>
+__global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
   static_assert(BNT == 128 || BNT == 64, "column tiles of 128 or 64");
+  static_assert(BMT == 128 || (BMT == 256 && BNT == 128), "row tiles of 128, or 256 x 128");
+  constexpr int NTH = BMT * 2;                          // threads per block
   constexpr int TN = BNT / 64;                          // 32-column MFMA tiles per wave
+  constexpr int AROW = BMT == 128 ? ROWB : 576;         // row pitch of an A plane (256 columns: 512 B + 64)
+  constexpr int APLANE = BK * AROW;
   constexpr int BROW = BNT == 128 ? ROWB : 192;         // row pitch of a B plane
   constexpr int BPLANE = BK * BROW;
-  constexpr int WSTAGE = OPER + 3 * BPLANE;             // A planes, then B planes
-  constexpr int B_CPR = BNT / 4;                        // 4-float chunks per B row
-  constexpr int B_F4 = BK * B_CPR / 256;                // B chunks per thread and step: 2 or 1
+  constexpr int AOPER = 3 * APLANE;
+  constexpr int WSTAGE = AOPER + 3 * BPLANE;            // A planes, then B planes
+  constexpr int A_CPR = BMT / 4, B_CPR = BNT / 4;       // 4-float chunks per row
+  constexpr int A_F4 = BK * A_CPR / NTH;                // A chunks per thread and step: 2
+  constexpr int B_F4 = BK * B_CPR / NTH;                // B chunks per thread and step: 2 or 1
+  static_assert(A_F4 * NTH == BK * A_CPR && B_F4 * NTH == BK * B_CPR && B_F4 >= 1, "whole chunks per thread");
   __shared__ __attribute__((aligned(16))) char lds[2 * WSTAGE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -87,16 +96,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
   const int lin = blockIdx.x, tq = lin >> 3, j = tq % gsz;
   const int split = (tq / gsz) * 8 + (lin & 7);
   if (split >= p.n_groups) return;                     // padding blocks of the last octet of splits (whole blocks leave)
-  const int m0 = (j % p.m_tiles) * BM, n0 = (j / p.m_tiles) * BNT;
+  const int m0 = (j % p.m_tiles) * BMT, n0 = (j / p.m_tiles) * BNT;
   const int kfull = p.Kt[tw] ? p.Kt[tw] : p.K;
   const int kbeg = split * p.ksplit, kend = min(kfull, kbeg + p.ksplit);
   const int nsteps = (kend - kbeg + BK - 1) / BK;
   const float* __restrict__ Ag = p.A[tw];
   const float* __restrict__ Bg = p.B[tw];
 
-  // staging map: A chunk c (4 columns) of rows (t >> 5) and (t >> 5) + 8 of each 16-row step; B chunk cb of rows
-  // krb + (256 / B_CPR) i
-  const int c = t & 31, kr = t >> 5;
+  // staging map: A chunk c (4 columns) of rows kr + (NTH / A_CPR) i of each 16-row step, B chunk cb of rows krb + (NTH / B_CPR) i
+  const int c = t % A_CPR, kr = t / A_CPR;
   const int cb = t % B_CPR, krb = t / B_CPR;
   constexpr bool PRO_VEC = PRO == PRO_NORM || PRO == PRO_LNSILU || PRO == PRO_LNELU;
   f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};
@@ -128,18 +136,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
     return o;
   };
 
-  f32x4 ra[2][2], rb[2][B_F4];                          // [register set = step parity][row]
+  f32x4 ra[2][A_F4], rb[2][B_F4];                       // [register set = step parity][row]
   auto gload = [&](int st, auto SET) {
     constexpr int S = decltype(SET)::value;
     const int k = kbeg + st * BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t kk = min(k + kr + 8 * i, kfull - 1);   // rows past the end are loaded clamped and zeroed when staged
+    for (int i = 0; i < A_F4; ++i) {
+      const int64_t kk = min(k + kr + (NTH / A_CPR) * i, kfull - 1);   // rows past the end are loaded clamped and zeroed when staged
       ra[S][i] = *reinterpret_cast<const f32x4*>(Ag + kk * p.lda + m0 + 4 * c);
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-      const int64_t kk = min(k + krb + (256 / B_CPR) * i, kfull - 1);
+      const int64_t kk = min(k + krb + (NTH / B_CPR) * i, kfull - 1);
       rb[S][i] = *reinterpret_cast<const f32x4*>(Bg + kk * p.ldb + n0 + 4 * cb);
     }
   };
@@ -149,19 +157,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
     char* buf = lds + S * WSTAGE;
     const int k = kbeg + st * BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_F4; ++i) {
       u32x2 h, m, l;
-      char* q = buf + (kr + 8 * i) * ROWB + c * 8;
-      split4(k + kr + 8 * i < kend ? ra[S][i] : zero, h, m, l);
+      const int row = kr + (NTH / A_CPR) * i;
+      char* q = buf + row * AROW + c * 8;
+      split4(k + row < kend ? ra[S][i] : zero, h, m, l);
       *reinterpret_cast<u32x2*>(q) = h;
-      *reinterpret_cast<u32x2*>(q + PLANE) = m;
-      *reinterpret_cast<u32x2*>(q + 2 * PLANE) = l;
+      *reinterpret_cast<u32x2*>(q + APLANE) = m;
+      *reinterpret_cast<u32x2*>(q + 2 * APLANE) = l;
     }
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
       u32x2 h, m, l;
-      const int row = krb + (256 / B_CPR) * i;
-      char* q = buf + OPER + row * BROW + cb * 8;
+      const int row = krb + (NTH / B_CPR) * i;
+      char* q = buf + AOPER + row * BROW + cb * 8;
       f32x4 v = rb[S][i];
       if constexpr (PRO != PRO_NONE) v = transform(v);
       split4(k + row < kend ? v : zero, h, m, l);
@@ -174,12 +183,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
   // fragment map of v_mfma_f32_32x32x16_bf16 through transposed reads: 16-lane group g takes columns 16 (g & 1) .. +15 and
   // rows 8 (g >> 1) .. +7 of the step; lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3
   const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int fa = (8 * (g >> 1) + q4) * ROWB + (16 * (g & 1) + 4 * p4) * 2 + (wm * 64) * 2;
-  const int fb = OPER + (8 * (g >> 1) + q4) * BROW + (16 * (g & 1) + 4 * p4) * 2 + (wn * 32 * TN) * 2;
-  auto tr_frag_b = [](const char* base) {               // tr_frag with the B row pitch
+  const int fa = (8 * (g >> 1) + q4) * AROW + (16 * (g & 1) + 4 * p4) * 2 + (wm * 64) * 2;
+  const int fb = AOPER + (8 * (g >> 1) + q4) * BROW + (16 * (g & 1) + 4 * p4) * 2 + (wn * 32 * TN) * 2;
+  auto tr_frag_p = [](const char* base, int pitch) {    // tr_frag with a plane's own row pitch
     typedef s16x4 __attribute__((address_space(3))) * lds_p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * BROW));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * pitch));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
   bf16x8 fra[2][2][3], frb[2][TN][3];                  // [fragment set = step parity][tile][plane]
@@ -189,9 +198,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const GemmP p) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fra[S][i][pl] = tr_frag(cur + fa + pl * PLANE + i * 64);
+      for (int i = 0; i < 2; ++i) fra[S][i][pl] = tr_frag_p(cur + fa + pl * APLANE + i * 64, AROW);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) frb[S][i][pl] = tr_frag_b(cur + fb + pl * BPLANE + i * 64);
+      for (int i = 0; i < TN; ++i) frb[S][i][pl] = tr_frag_p(cur + fb + pl * BPLANE + i * 64, BROW);
     }
   };
 
