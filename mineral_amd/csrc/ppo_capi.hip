@@ -413,9 +413,10 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
 
 // input gradients of the wide layers (N a multiple of 128, K of 16) through dgrad_split_kernel; same grid as the fp32 launch
 static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
-  static int cls = prof_register("mrl::dgrad_split_kernel");
+  static int cls_planes = prof_register("mrl::dgrad_split_kernel<true>"), cls_split = prof_register("mrl::dgrad_split_kernel<false>");
   bool planes = p.Bpl[0] != nullptr;                  // 16-byte plane chunks need weight matrices that start on a multiple of 8 elements
   for (unsigned z = 0; z < grid.z; ++z) planes = planes && p.Bpl[z] && ((uintptr_t)p.Bpl[z] % 16 == 0);
+  const int cls = planes ? cls_planes : cls_split;
   const bool timed = g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
