@@ -82,7 +82,8 @@ def make_critic(O, units, n_critics, seed):
     return c, pc
 
 
-@pytest.mark.parametrize('rows,O,units,n_critics', [(300, 40, [256, 128], 2), (64, 8, [32, 32], 1), (1000, 60, [512, 256, 128], 2)])
+@pytest.mark.parametrize('rows,O,units,n_critics', [(300, 40, [256, 128], 2), (64, 8, [32, 32], 1), (1000, 60, [512, 256, 128], 2),
+                                                     (8193, 40, [256, 128], 2)])   # one row into the split-bf16 regime: ragged last tiles and steps
 def test_values_and_gradient_vs_oracle(rows, O, units, n_critics):
     from mineral_amd.agents.diffrl import CriticLearner
     c, pc = make_critic(O, units, n_critics, 31)
