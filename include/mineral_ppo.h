@@ -9,7 +9,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued, nothing syncs
  *   - every function returns 0 on success or a negative MRL_E* code; mrl_last_error() gives the message of the
  *     calling thread's last failure.  Nothing here allocates device memory: callers pass workspaces sized by
- *     mrl_workspace_bytes().
+ *     mrl_workspace_bytes() and aligned to 256 bytes (hipMalloc and torch allocations are); a workspace only has to
+ *     outlive the calls that use it, and calls that share one must not overlap.
  *   - layouts: the rollout buffer is ENV-MAJOR for per-sample vectors, so the flat sample index of
  *     (env n, step t) is n*T + t — exactly the index map produced by transpose(0,1)+reshape in
  *     mineral/agents/ppo/experience.py:7-14 — and minibatch i is the contiguous row range [i*mb, (i+1)*mb)

@@ -1182,6 +1182,7 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
   Workspace W;
   workspace_layout(net, N, &W);
   if (workspace_bytes < W.total * 4) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)W.total * 4);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   ParamLayout L;
   param_layout(net, &L);
   hipStream_t s = (hipStream_t)stream;
@@ -1260,6 +1261,7 @@ extern "C" int mrl_gae_scan(const mrl_rollout* buf, const float* last_values, do
   const int nblocks = (int)cdiv(N, 64);
   const int64_t need = (int64_t)nblocks * 6 * 8;
   if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   size_t smem = (size_t)4 * 64 * (T + 1) * sizeof(float);
   if (smem > 64 * 1024) MRL_FAIL(MRL_EINVAL, "horizon %d too long for the scan tile", T);
   hipStream_t s = (hipStream_t)stream;
@@ -1309,6 +1311,7 @@ extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, 
   const int nblocks = (int)cdiv(buf->num_envs, 64);
   const int64_t need = (int64_t)nblocks * 6 * 8 + 6 * 8 + 8 * 4;
   if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   double* sums = (double*)workspace + (int64_t)nblocks * 6;
   float* stats = stats_out ? stats_out : (float*)(sums + 6);
   int rc = mrl_gae_scan(buf, last_values, gamma, tau, sums, workspace, workspace_bytes, stream);
@@ -1329,6 +1332,7 @@ extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int
   if (groups > 65535) MRL_FAIL(MRL_EINVAL, "too many groups");
   const int64_t need = groups * chunks * 2 * cols * 8;
   if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   hipStream_t s = (hipStream_t)stream;
   const int rowlanes = 256 / cols > 0 ? 256 / cols : 1;
   size_t smem = (size_t)2 * rowlanes * cols * sizeof(double);
@@ -1543,6 +1547,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   Workspace W;
   workspace_layout(net, mb, &W);
   if (workspace_bytes < W.total * 4) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)W.total * 4);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   ParamLayout L;
   param_layout(net, &L);
   hipStream_t s = (hipStream_t)stream;

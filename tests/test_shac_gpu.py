@@ -250,3 +250,18 @@ def test_split_bf16_gemm_gradients_against_an_fp64_oracle(rows, O, units):
         err_cpu = max(err_cpu, (g32[k].double() - ref).abs().max().item() / scale)
     assert err_dev <= 2e-6, (err_dev, err_cpu)
     assert err_dev <= err_cpu, (err_dev, err_cpu)
+
+
+def test_misaligned_workspace_is_rejected():
+    """Workspaces hold 16-byte vectors and doubles at offsets the library computes from the base: a base that is not
+    256-byte aligned is refused before anything is launched."""
+    from mineral_amd import _hip
+    c, _ = make_critic(12, [64, 64], 1, 3)
+    obs = synth.gaussianish((64, 12), 3).to(DEV)
+    out = torch.empty(1, 64, dtype=torch.float32, device=DEV)
+    need = int(_hip.lib().mrl_critic_workspace_bytes(c.net, 64))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device=DEV)
+    rc = _hip.lib().mrl_critic_values(c.net, _hip.ptr(c.flat), _hip.ptr(obs), 64, None, None, 0.0, 0.0, _hip.ptr(out), C.c_void_p(ws.data_ptr() + 4), need, stream())
+    assert rc == -1 and b'aligned' in _hip.lib().mrl_last_error()
+    _hip.check(_hip.lib().mrl_critic_values(c.net, _hip.ptr(c.flat), _hip.ptr(obs), 64, None, None, 0.0, 0.0, _hip.ptr(out), _hip.ptr(ws), need, stream()),
+               'mrl_critic_values')
