@@ -557,10 +557,6 @@ static __device__ __forceinline__ float add_rn(float a, float b) { return a + b;
 static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 static __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 
-__global__ void fill_zero_kernel(float* __restrict__ p, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
-}
-
 __global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int cols4,
                                  int64_t dst_row_stride4, int64_t dst_off4) {
   // src [rows][cols] contiguous -> dst[row*stride + off + c]; all in float4 units
@@ -1501,9 +1497,8 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
 static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, float* grads, int tw0, int towers, int hblocks,
                                hipStream_t s) {
   const int nl = net->n_layers, U = net->units[nl - 1];
-  // alignment gaps between tensors of the flat gradient are never produced by a kernel: start from zeros
-  // (a fill kernel, not hipMemsetAsync, so that the sequence can be captured in a graph)
-  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)cdiv(L.total, 1024)), dim3(256), 0, s, grads, L.total);
+  // Every float of the flat gradient is written below: tensor sizes are multiples of 4 floats except the head biases, whose
+  // descriptors are rounded up to whole 4-float chunks (zero columns of the partials), and the layout pads offsets to 4.
   ReduceTable tab;
   tab.n = 0;
   auto add = [&](const float* src, int64_t off, int64_t count, int64_t stride, int nslabs) {
