@@ -78,7 +78,8 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
 
 
-@pytest.mark.parametrize('O,A,au,cu,B', [(8, 4, [64, 32], [64, 32], 48), (64, 12, [512, 256, 128], [512, 256, 128], 300), (12, 4, [128], [256, 64], 129)])
+@pytest.mark.parametrize('O,A,au,cu,B', [(8, 4, [64, 32], [64, 32], 48), (64, 12, [512, 256, 128], [512, 256, 128], 300), (12, 4, [128], [256, 64], 129),
+                                          (64, 12, [512, 256, 128], [512, 256, 128], 8200)])   # above 8,192 rows: the split-bf16 GEMMs, incl. the input gradient through the critic
 def test_sac_gradients_vs_oracle(O, A, au, cu, B):
     from mineral_amd import _hip
     L = _hip.lib()
