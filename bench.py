@@ -132,7 +132,9 @@ def main():
     torch.manual_seed(671155 + rank)      # 'train' sub-seed (action noise)
     env = synthetic.make_envs(cfg)
     logdir = os.path.join('/tmp', f'mrl_bench_{os.getpid()}')
-    agent = PPO(cfg, logdir=logdir, accelerator=None, datasets=None, env=env)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the agent prints its model like the reference does; stdout carries the JSON line only
+        agent = PPO(cfg, logdir=logdir, accelerator=None, datasets=None, env=env)
     agent.obs = agent._convert_obs(env.reset())
 
     def one_step():
