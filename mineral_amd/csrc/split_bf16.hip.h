@@ -8,6 +8,8 @@
 // hh, hm, mh, mm, hl, lh; the three dropped terms are below 2^-24 of |a*b|, the rounding of an fp32 product itself.  Against
 // an fp64 sum the result is closer than a sequential fp32 fma chain (2e-8 against 1.5e-7 of sum|a*b| over 32,768 rows,
 // tools/bf16x3_split_probe.hip).  Six v_mfma_f32_32x32x16_bf16 (16 k each) replace eight v_mfma_f32_32x32x2_f32 twice as long.
+// Non-finite operands: an infinite element splits into (inf, NaN, NaN), so it contributes NaN where the fp32 MFMA would give
+// +-inf; NaN stays NaN.  Finite operands of any magnitude are exact.
 //
 // Tiles: 128 x 128 per 256-thread block (2 x 2 waves of 64 x 64), 16 reduction indices per step.  An operand whose rows are
 // the reduction index keeps each plane as an LDS image [16 rows][128 columns] of bf16 in its own row-major order, and the
