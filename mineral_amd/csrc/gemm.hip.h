@@ -135,6 +135,34 @@ __device__ __forceinline__ float sigmoid_fast(float y) {
 __device__ __forceinline__ float silu_f(float y) { return y / (1.0f + expf(-y)); }
 __device__ __forceinline__ float sigmoid_f(float y) { return 1.0f / (1.0f + expf(-y)); }
 
+// Exact three-term bf16 split of fp32 values for the split-bf16 GEMMs: x = h + m + l with h = bf16(x), m = bf16(x - h),
+// l = x - h - m, each rounded to nearest even (v_cvt_pk_bf16_f32 converts and packs two values at once).  x - h and
+// (x - h) - m are exact in fp32 and the last remainder has at most 8 significant bits, so nothing is lost; rounding to
+// nearest keeps |m| <= 2^-8 |x| and |l| <= 2^-16 |x| with either sign, so the three product terms the GEMMs drop (ml, lm,
+// ll) stay below 2^-23 |a b| and do not bias the sum.  |x| must stay below 3.38e38 (beyond it h rounds to infinity).
+typedef __bf16 split_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int split_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned split_pack2(float a, float b) {
+  const split_bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// the fp32 values of the two halves of a packed pair (v_perm keeps the compiler from converting the low element twice)
+__device__ __forceinline__ float split_lo(unsigned pk) { return __uint_as_float(__builtin_amdgcn_perm(pk, 0u, 0x05040c0cu)); }
+__device__ __forceinline__ float split_hi(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+__device__ __forceinline__ void split_rne4(const f32x4 x, split_u32x2& h, split_u32x2& m, split_u32x2& l) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = x[2 * e], x1 = x[2 * e + 1];
+    const unsigned hp = split_pack2(x0, x1);
+    const float r0 = x0 - split_lo(hp), r1 = x1 - split_hi(hp);
+    const unsigned mp = split_pack2(r0, r1);
+    const float s0 = r0 - split_lo(mp), s1 = r1 - split_hi(mp);
+    h[e] = hp;
+    m[e] = mp;
+    l[e] = split_pack2(s0, s1);
+  }
+}
+
 // Tile-relative buffer addressing for the epilogues: one descriptor per block tile (uniform), one 32-bit byte offset
 // per lane, and a compile-time scalar offset per element -- no per-element 64-bit address registers.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -469,13 +497,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
 
   constexpr int NG = BK / 8;   // k sub-steps per tile
   if constexpr (MM == 1) {
-    // Every fp32 operand element is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by
-    // truncation) and each product is accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms
-    // are below 2^-24 of |a*b|.  Planes live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on
+    // Every fp32 operand element is split exactly into three bf16 terms x = h + m + l (split_rne4) and each product is
+    // accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-23 of |a*b|.  Planes live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on
     // every other group of 8 rows (a quarter-wave's 16-byte fragment reads then cover all banks).  Per step: the MFMAs of
     // step st from stage st & 1, then the operands of step st+1 (in registers since two steps) are split into the other
     // stage and the loads of step st+3 issued; one barrier per step.
-    using sp_u32x2 = unsigned int __attribute__((ext_vector_type(2)));
     using sp_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
     constexpr int ROWS = BM + BN, SPLANE = ROWS * 32, SSTAGE = 3 * SPLANE;
     constexpr int A_CH = BM * 4 / NT, B_CH = BN * 4 / NT;           // 16-byte chunks per thread and step
@@ -504,23 +530,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       }
     };
     auto sp_split = [&](const f32x4 x, char* q) {
-      unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned xb = __float_as_uint(x[e]);
-        hb[e] = xb & 0xffff0000u;
-        const float r1 = x[e] - __uint_as_float(hb[e]);
-        mb[e] = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mb[e]);
-        lb[e] = __float_as_uint(r2);                                 // at most 8 significant bits are left: its upper half is exact
-      }
-      sp_u32x2 w;
-      w[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-      *reinterpret_cast<sp_u32x2*>(q) = w;
-      w[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-      *reinterpret_cast<sp_u32x2*>(q + SPLANE) = w;
-      w[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); w[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
-      *reinterpret_cast<sp_u32x2*>(q + 2 * SPLANE) = w;
+      split_u32x2 h, m, l;
+      split_rne4(x, h, m, l);
+      *reinterpret_cast<split_u32x2*>(q) = h;
+      *reinterpret_cast<split_u32x2*>(q + SPLANE) = m;
+      *reinterpret_cast<split_u32x2*>(q + 2 * SPLANE) = l;
     };
     auto sp_stage = [&](auto SET) {
       constexpr int S = decltype(SET)::value;

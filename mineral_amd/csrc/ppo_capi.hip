@@ -467,13 +467,13 @@ __global__ void split_params_kernel(const float* __restrict__ params, int64_t n,
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float x = params[i];
-  const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mb);
-  planes[i] = (unsigned short)(hb >> 16);
-  planes[stride + i] = (unsigned short)(mb >> 16);
-  planes[2 * stride + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+  const unsigned hp = split_pack2(x, 0.f);            // the split of split_rne4, one value at a time
+  const float r1 = x - split_lo(hp);
+  const unsigned mp = split_pack2(r1, 0.f);
+  const float r2 = r1 - split_lo(mp);
+  planes[i] = (unsigned short)hp;
+  planes[stride + i] = (unsigned short)mp;
+  planes[2 * stride + i] = (unsigned short)split_pack2(r2, 0.f);
 }
 
 static unsigned short* launch_split_params(const ParamLayout& L, const Workspace& W, float* ws, const float* params, hipStream_t s) {

@@ -3,13 +3,14 @@
 //   wgrad:  slab[split][m][n] = sum over the split's batch rows k of A[k][m] * f(B[k][n])    A = dZ, B = the layer input, f = prologue
 //   dgrad:  out[m][n] = sum_k A[m][k] * B[k][n]                                              A = dZ of the layer above, B = its weights
 //
-// Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by truncation; bf16 has
-// the exponent range of fp32, so nothing under- or overflows), and each product is accumulated in fp32 from the six terms
-// hh, hm, mh, mm, hl, lh; the three dropped terms are below 2^-24 of |a*b|, the rounding of an fp32 product itself.  Against
-// an fp64 sum the result is closer than a sequential fp32 fma chain (2e-8 against 1.5e-7 of sum|a*b| over 32,768 rows,
+// Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, rounded to nearest; bf16
+// has the exponent range of fp32, so small values do not underflow), and each product is accumulated in fp32 from the six
+// terms hh, hm, mh, mm, hl, lh; the three dropped terms are below 2^-23 of |a*b| with either sign, the size of the rounding
+// of an fp32 product itself.  Against
+// an fp64 sum the result is closer than a sequential fp32 fma chain (1.4e-8 against 1.5e-7 of sum|a*b| over 32,768 rows,
 // tools/bf16x3_split_probe.hip).  Six v_mfma_f32_32x32x16_bf16 (16 k each) replace eight v_mfma_f32_32x32x2_f32 twice as long.
 // Non-finite operands: an infinite element splits into (inf, NaN, NaN), so it contributes NaN where the fp32 MFMA would give
-// +-inf; NaN stays NaN.  Finite operands of any magnitude are exact.
+// +-inf; NaN stays NaN.  Finite operands below 3.38e38 in magnitude are exact.
 //
 // Tiles: 128 x 128 per 256-thread block (2 x 2 waves of 64 x 64), 16 reduction indices per step.  An operand whose rows are
 // the reduction index keeps each plane as an LDS image [16 rows][128 columns] of bf16 in its own row-major order, and the
@@ -37,26 +38,8 @@ constexpr int ROWB = 320;           // bytes per row of a plane: 128 bf16 + 64 B
 constexpr int PLANE = BK * ROWB;    // 5,120 B
 constexpr int OPER = 3 * PLANE;     // three planes per operand
 
-// x (4 floats) -> three packed bf16 quadruples with x = h + m + l exactly
-__device__ __forceinline__ void split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
-  unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned xb = __float_as_uint(x[e]);
-    hb[e] = xb & 0xffff0000u;
-    const float r1 = x[e] - __uint_as_float(hb[e]);
-    mb[e] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb[e]);
-    lb[e] = __float_as_uint(r2);                      // at most 8 significant bits are left: its upper half is exact
-  }
-  // low half = upper 16 bits of the even element, high half = upper 16 bits of the odd one
-  h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
-  h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-  m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
-  m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-  l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
-  l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
-}
+// x (4 floats) -> three packed bf16 quadruples with x = h + m + l exactly (split_rne4, gemm.hip.h)
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) { split_rne4(x, h, m, l); }
 
 // Two transposed 4-row blocks (rows k .. k+3 and k+4 .. k+7 of this lane's column) make one MFMA fragment.  Every lane of
 // the wave must take part (the gather crosses lanes): callers keep the whole block active.

@@ -2,8 +2,8 @@
 //
 //   C[z][m][n] = sum_k A[z][k][m] * B[z][k][n]        (A = dZ [rows][out], B = X [rows][in]; both row-major, k = batch row)
 //
-// Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, by truncation), and the
-// product is accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh (the dropped ones are below 2^-24 of |a*b|): six
+// Every fp32 operand is split exactly into three bf16 terms x = h + m + l (8 significant bits each, rounded to nearest), and the
+// product is accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh (the dropped ones are below 2^-23 of |a*b|): six
 // v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 k) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each, 2 k): 192 against
 // 512 matrix-core cycles per 16 k.  The probe measures what is left of that 2.7x once the split (VALU) and the staging are
 // paid, and the error against an fp64 sum next to that of a plain fp32 sum.
@@ -48,25 +48,26 @@ constexpr int PLANE = BK * ROWB;          // 5,120 B
 constexpr int OPER = 3 * PLANE;           // three planes per operand
 constexpr int STAGE = 2 * OPER;           // A and B of one k-step: 30,720 B; two stages in flight
 
-// x (4 floats) -> three packed bf16 quadruples (exact: x = h + m + l)
+// x (4 floats) -> three packed bf16 quadruples (exact: x = h + m + l), every term rounded to nearest even
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float lo_f(unsigned pk) { return __uint_as_float(__builtin_amdgcn_perm(pk, 0u, 0x05040c0cu)); }
+__device__ __forceinline__ float hi_f(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
 __device__ __forceinline__ void split4(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
-  unsigned hb[4], mb[4], lb[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned xb = __float_as_uint(x[e]);
-    hb[e] = xb & 0xffff0000u;
-    const float r1 = x[e] - __uint_as_float(hb[e]);
-    mb[e] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb[e]);
-    lb[e] = __float_as_uint(r2);
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = x[2 * e], x1 = x[2 * e + 1];
+    const unsigned hp = pack2(x0, x1);
+    const float r0 = x0 - lo_f(hp), r1 = x1 - hi_f(hp);
+    const unsigned mp = pack2(r0, r1);
+    const float s0 = r0 - lo_f(mp), s1 = r1 - hi_f(mp);
+    h[e] = hp;
+    m[e] = mp;
+    l[e] = pack2(s0, s1);
   }
-  // low half = element 0 (its upper 16 bits), high half = element 1
-  h[0] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
-  h[1] = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
-  m[0] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
-  m[1] = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
-  l[0] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
-  l[1] = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* base) {
