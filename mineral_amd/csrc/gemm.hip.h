@@ -498,10 +498,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   constexpr int NG = BK / 8;   // k sub-steps per tile
   if constexpr (MM == 1) {
     // Every fp32 operand element is split exactly into three bf16 terms x = h + m + l (split_rne4) and each product is
-    // accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-23 of |a*b|.  Planes live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on
-    // every other group of 8 rows (a quarter-wave's 16-byte fragment reads then cover all banks).  Per step: the MFMAs of
-    // step st from stage st & 1, then the operands of step st+1 (in registers since two steps) are split into the other
-    // stage and the loads of step st+3 issued; one barrier per step.
+    // accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-23 of |a*b|.  Planes
+    // live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on every other group of 8 rows (a
+    // quarter-wave's 16-byte fragment reads then cover all banks).  Per step: the MFMAs of step st from stage st & 1, then
+    // the operands of step st+1 (already in registers) are split into the other stage and the next loads issued; one
+    // barrier per step (NBUF 2), or one stage and two barriers per step for short reductions (NBUF 1).
     using sp_bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
     constexpr int ROWS = BM + BN, SPLANE = ROWS * 32, SSTAGE = 3 * SPLANE;
     constexpr int A_CH = BM * 4 / NT, B_CH = BN * 4 / NT;           // 16-byte chunks per thread and step
