@@ -152,7 +152,10 @@ static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
   w.bn = (w.bm == 32) ? 128 : (gn <= 64 ? 64 : 128);
   w.tiles_m = (int)cdiv(gm, w.bm);
   w.tiles_n = (int)cdiv(gn, w.bn);
-  int64_t want = cdiv(512, (int64_t)w.tiles_m * w.tiles_n * 2);
+  // blocks wanted per tower: two per CU; one per CU for the gradients of one or two tiles on large batches, whose blocks
+  // would otherwise store a slab after 16 steps (measured: 128 / 256 / 512 -> 259.5 / 250.8 / 253.0 ms per update)
+  const int64_t blocks = (w.tiles_m * w.tiles_n <= 2 && rows > 8192) ? 256 : 512;
+  int64_t want = cdiv(blocks, (int64_t)w.tiles_m * w.tiles_n * 2);
   int64_t ks = cdiv(cdiv(rows, want), 16) * 16;
   if (ks < 64) ks = 64;
   w.ksplit = (int)ks;
