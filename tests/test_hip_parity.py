@@ -263,6 +263,10 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
     ('odd_heads', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    # the benchmark's own launches: the DFlexAntPPO network on 32768-row minibatches (256-block weight-gradient plans, 256-row
+    # tiles, 256 row tiles per tower), as the only minibatch of the batch and as the second of two (row0 = 32768)
+    ('full', 1024, 32, 32768, 'dreamerv3_normal', 0, 'bound'),
+    ('full', 2048, 32, 32768, 'dreamerv3_normal', 0, 'bound'),
 ])
 def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
     spec = NETS[net]
@@ -341,6 +345,46 @@ def test_ppo_grad_and_adam(hip, net, N, T, mb, dist, clipv, btype):
         mv = model.views_of(m1)
         for name in p_ref:
             assert_close(cpu(mv[name]), st['exp_avg'][name], 1e-5, 1e-10, f'{optim} exp_avg {name}')
+
+
+def test_benchmark_minibatch_gradients_against_an_fp64_oracle(hip):
+    """The 32768-row minibatch of the benchmark through the split-bf16 GEMMs.  Truth: the oracle evaluated in fp64; yardstick:
+    the oracle in fp32 on the CPU.  The device gradient must be within 5e-6 of each tensor's largest entry of the truth
+    (60 times tighter than the fp32-vs-fp32 tolerance of test_ppo_grad_and_adam; measured 1.5e-6) and at least as close
+    to it as the fp32 CPU result is (measured 4.6e-6)."""
+    spec = NETS['full']
+    N, T, mb = 1024, 32, 32768
+    params = oracle_params(spec, 9)
+    cfg = oracle_cfg(spec)
+    model = make_model(spec, params)
+    buf = make_buffer(spec, N, T, mb)
+    data = _fill_training_buffer(spec, buf, N, T)
+    hp = O.PPOHParams(horizon_len=T, minibatch_size=mb, entropy_coef=0.01)
+    chp = hip.PpoHp(hp.e_clip, hp.critic_coef, hp.entropy_coef, hp.bounds_loss_coef, 0, 0, 0)
+    L = hip.lib()
+    ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
+    grads = torch.full((model.param_count,), float('nan'), device=DEV)
+    metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
+    hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, 0, mb, None, None, 0.0, 0.0, hip.ptr(grads), hip.ptr(metrics),
+                             hip.ptr(ws), ws.numel(), None), 'grad')
+
+    def oracle_grads(dtype):
+        leaves = {k: v.to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+        mbd = {k: v.to(dtype) for k, v in data.items()}
+        out = O.model_forward(leaves, mbd['obs'], mbd['actions'], cfg)
+        loss, _ = O.total_loss(out, mbd, hp)
+        return dict(zip(leaves, torch.autograd.grad(loss, list(leaves.values()))))
+
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    gv = model.views_of(grads)
+    err_dev = err_cpu = 0.0
+    for k, ref in g64.items():
+        scale = ref.abs().max().item()
+        err_dev = max(err_dev, (cpu(gv[k]).double() - ref).abs().max().item() / scale)
+        err_cpu = max(err_cpu, (g32[k].double() - ref).abs().max().item() / scale)
+    print(f'fp64-oracle distance: device {err_dev:.3e}, fp32 CPU {err_cpu:.3e}')
+    assert err_dev <= 5e-6, (err_dev, err_cpu)
+    assert err_dev <= err_cpu, (err_dev, err_cpu)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
