@@ -158,6 +158,15 @@ int mrl_gae_scan(const mrl_rollout* buf, const float* last_values, double gamma,
 int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, double count, const mrl_rms* value_rms,
                       float* stats_out, void* stream);
 
+/* No counterpart in the reference: mrl_gae_finish for callers that cannot allocate device memory or pass a workspace
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same arguments, kernels and
+ * results as mrl_gae_finish, but the scratch (per-block partial sums, sums, statistics) lives in a device array built
+ * into the library: 786,688 bytes that every GPU the library runs on holds until the process ends.  At most 1,048,576
+ * envs (MRL_EINVAL beyond that).  Allocates nothing.  The device that owns `stream` must be the current device.  All
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+int mrl_gae_finish_static(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
+                          const mrl_rms* value_rms, float* stats_out, void* stream);
+
 /* Batch moments of x [rows][cols] per group of `group_rows` consecutive rows: mean (fp32) and variance with the
  * given correction (fp32), as x.mean(0) / x.var(0, correction) in RunningMeanStd.update
  * (normalizers.py:57-63).  Outputs are [rows/group_rows][cols]. */

@@ -97,6 +97,7 @@ _SIGNATURES = {
     'mrl_rollout_write': (C.c_int, [C.POINTER(Rollout), C.c_int32, _P, _P, _P, C.c_double, C.c_double, _P]),
     'mrl_episode_update': (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     'mrl_gae_finish': (C.c_int, [C.POINTER(Rollout), _P, C.c_double, C.c_double, C.POINTER(Rms), _P, _P, C.c_int64, _P]),
+    'mrl_gae_finish_static': (C.c_int, [C.POINTER(Rollout), _P, C.c_double, C.c_double, C.POINTER(Rms), _P, _P]),
     'mrl_gae_scan': (C.c_int, [C.POINTER(Rollout), _P, C.c_double, C.c_double, _P, _P, C.c_int64, _P]),
     'mrl_gae_normalize': (C.c_int, [C.POINTER(Rollout), _P, C.c_double, C.POINTER(Rms), _P, _P]),
     'mrl_batch_moments': (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P]),

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <utility>
 #include <vector>
 
@@ -1316,6 +1317,44 @@ extern "C" int mrl_gae_finish(const mrl_rollout* buf, const float* last_values, 
   int rc = mrl_gae_scan(buf, last_values, gamma, tau, sums, workspace, workspace_bytes, stream);
   if (rc) return rc;
   return mrl_gae_normalize(buf, sums, (double)(buf->num_envs * (int64_t)buf->horizon), value_rms, stats, stream);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------------------------
+// mrl_gae_finish with its scratch (per-block partial sums, the six sums, the statistics) in a file-scope device array
+// instead of a caller workspace.  Every GPU the library runs on holds its own copy of the array at its own address;
+// the address is looked up once per device, with that device current, and kept.  Nothing in the scratch has to start
+// at zero: gae_kernel writes every partial that gae_sums_kernel reads, and the sums / statistics are written before
+// they are read, so the contents left by an earlier (larger) call are never consumed.
+constexpr int64_t MRL_STATIC_GAE_MAX_ENVS = (int64_t)1 << 20;
+constexpr int64_t MRL_STATIC_SCRATCH_BYTES = (MRL_STATIC_GAE_MAX_ENVS / 64) * 6 * 8 + 256;   // 786,688 bytes per GPU
+static __device__ __align__(256) unsigned char scratch[MRL_STATIC_SCRATCH_BYTES];
+constexpr int MRL_MAX_DEVICES = 64;
+static std::atomic<void*> g_scratch_ptr[MRL_MAX_DEVICES];
+
+static int static_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) MRL_FAIL(MRL_EHIP, "hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= MRL_MAX_DEVICES) MRL_FAIL(MRL_EINVAL, "device %d outside 0..%d", dev, MRL_MAX_DEVICES - 1);
+  void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!ptr) {
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));   // the address of THIS device's copy (the current device)
+    if (e != hipSuccess || !ptr) MRL_FAIL(MRL_EHIP, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev].store(ptr, std::memory_order_release);   // concurrent first calls look up the same address
+  }
+  *out = ptr;
+  return MRL_OK;
+}
+
+extern "C" int mrl_gae_finish_static(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
+                                     const mrl_rms* value_rms, float* stats_out, void* stream) {
+  if (check_buf(buf)) return MRL_EINVAL;
+  if (buf->num_envs > MRL_STATIC_GAE_MAX_ENVS)
+    MRL_FAIL(MRL_EINVAL, "mrl_gae_finish_static: %lld envs exceed the built-in scratch (at most %lld envs; use mrl_gae_finish with a workspace)",
+             (long long)buf->num_envs, (long long)MRL_STATIC_GAE_MAX_ENVS);
+  void* ptr = nullptr;
+  if (int rc = static_scratch(&ptr)) return rc;
+  return mrl_gae_finish(buf, last_values, gamma, tau, value_rms, stats_out, ptr, MRL_STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int64_t group_rows, int32_t correction,
