@@ -173,6 +173,22 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def require_current_device(device):
+    """The library launches its kernels on the CURRENT HIP device and never selects one itself.  Pointers that live on
+    another GPU would be dereferenced by a kernel running on the current one (a memory fault without peer access), so the
+    host classes call this once at construction and refuse a device that is not current."""
+    import torch
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise HipLibraryError(f'device {device} is not a GPU; the HIP path has no CPU fallback')
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_device()
+    if index != cur:
+        raise HipLibraryError(f'tensors live on cuda:{index} but the current device is cuda:{cur}: call torch.cuda.set_device({index}) '
+                              'before constructing the agent (the launcher does)')
+    return index
+
+
 TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1}   # (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
 
 

@@ -41,6 +41,7 @@ class PPO(Agent):
         if list(self.obs_space.keys()) != ['obs']:
             raise NotImplementedError('dict observations are outside the device PPO path')
         dev = torch.device(self.device)
+        _hip.require_current_device(dev)
 
         # --- Normalizers (ppo.py:29-43) ---
         rms_config = dict(eps=1e-5, with_clamp=True, initial_count=1, dtype=torch.float64, device=dev)
@@ -65,8 +66,11 @@ class PPO(Agent):
         self.optim_type = self.ppo_config.optim_type
         if self.optim_type not in ('Adam', 'AdamW'):
             raise NotImplementedError(self.optim_type)
-        self.init_lr = float(optim_kwargs.get('lr', 3e-4 if self.optim_type == 'Adam' else 1e-3))
+        self.init_lr = float(optim_kwargs.get('lr', 3e-4))   # ppo.py:60
         self.last_lr = self.init_lr
+        # the learning rate the optimizer holds (param_group['lr']): the reference copies last_lr into it at the end of every
+        # mini-epoch (ppo.py:344-345), so a 'linear' update made after the loop (ppo.py:347-348) takes effect one mini-epoch late
+        self._optim_lr = self.init_lr
         self.betas = tuple(optim_kwargs.get('betas', (0.9, 0.999)))
         self.adam_eps = float(optim_kwargs.get('eps', 1e-8))
         self.weight_decay = float(optim_kwargs.get('weight_decay', 0.01 if self.optim_type == 'AdamW' else 0.0))
@@ -116,8 +120,8 @@ class PPO(Agent):
 
         # --- Scratch: sized once for max(num_envs, minibatch) rows; nothing is allocated inside the loops ---
         L = _hip.lib()
-        rows = max(self.num_actors, self.minibatch_size)
-        ws_bytes = int(L.mrl_workspace_bytes(self.model.net, rows))
+        # the layout is not monotone in the row count (tile heights and split plans change with it): size for both uses
+        ws_bytes = max(int(L.mrl_workspace_bytes(self.model.net, self.num_actors)), int(L.mrl_workspace_bytes(self.model.net, self.minibatch_size)))
         n_mb = max(1, self.batch_size // self.minibatch_size)
         mom_bytes = n_mb * 1024 * 2 * self.model.obs_dim * 8 + 65536
         self._ws = torch.empty(max(ws_bytes, mom_bytes), dtype=torch.uint8, device=dev)
@@ -294,7 +298,7 @@ class PPO(Agent):
                     parallel.average_gradients(self.grads, self._dist)   # the one collective per optimizer step (ppo.py:292)
                 self.optim_step += 1
                 _hip.check(L.mrl_adam_step(_hip.ptr(flat), _hip.ptr(self.grads), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
-                                           flat.numel(), self.last_lr, self.betas[0], self.betas[1], self.adam_eps,
+                                           flat.numel(), self._optim_lr, self.betas[0], self.betas[1], self.adam_eps,
                                            self.weight_decay, adamw, self.optim_step, max_norm, grad_scale,
                                            _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_adam_step')
                 k += 1
@@ -308,6 +312,7 @@ class PPO(Agent):
             elif self.lr_schedule == 'cos':
                 self.last_lr = adjust_learning_rate_cos(self.init_lr, mini_ep, self.mini_epochs, self.agent_steps,
                                                         self.max_agent_steps)
+            self._optim_lr = self.last_lr                                  # ppo.py:344-345
         if self.lr_schedule == 'linear':
             self.last_lr = self.scheduler.update(self.agent_steps)
         m = self._metrics[:k]
@@ -370,7 +375,7 @@ class PPO(Agent):
         if self.optim_step > 0:
             for i, n in enumerate(names):
                 state[i] = {'step': torch.tensor(float(self.optim_step)), 'exp_avg': m[n].clone(), 'exp_avg_sq': v[n].clone()}
-        group = {'lr': self.last_lr, 'betas': self.betas, 'eps': self.adam_eps, 'weight_decay': self.weight_decay,
+        group = {'lr': self._optim_lr, 'betas': self.betas, 'eps': self.adam_eps, 'weight_decay': self.weight_decay,
                  'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
                  'fused': None, 'params': list(range(len(names)))}
         return {'state': state, 'param_groups': [group]}
@@ -388,7 +393,7 @@ class PPO(Agent):
             step = int(float(st['step']))
         self.optim_step = step
         if sd.get('param_groups'):
-            self.last_lr = float(sd['param_groups'][0]['lr'])
+            self._optim_lr = float(sd['param_groups'][0]['lr'])   # last_lr itself is not checkpointed (ppo.py:416-426)
 
     def save(self, f):
         ckpt = {

@@ -65,6 +65,7 @@ class SAC(Agent):
         _hip.lib()
         if not str(self.device).startswith('cuda'):
             raise _hip.HipLibraryError(f'the SAC update loop runs on an MI355X only (rl_device={self.device}); no CPU fallback')
+        _hip.require_current_device(self.device)
         if list(self.obs_space.keys()) != ['obs']:
             raise NotImplementedError('dict observations are outside the device SAC path')
         if self.network_config.get('encoder', None) is not None:
@@ -129,8 +130,9 @@ class SAC(Agent):
 
         # --- Scratch, sized once ---
         L = _hip.lib()
-        rows = max(self.num_actors, int(c.batch_size))
-        self._ws = torch.empty(int(L.mrl_sac_workspace_bytes(self.net, rows)), dtype=torch.uint8, device=dev)
+        # the layout is not monotone in the row count (tile heights and split plans change with it): size for both uses
+        ws_bytes = max(int(L.mrl_sac_workspace_bytes(self.net, self.num_actors)), int(L.mrl_sac_workspace_bytes(self.net, int(c.batch_size))))
+        self._ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self._mean_f = torch.zeros(O, dtype=torch.float32, device=dev)
         self._std_f = torch.ones(O, dtype=torch.float32, device=dev)
         self._metrics_c = torch.zeros(int(c.mini_epochs), _hip.SAC_NMETRIC, dtype=torch.float64, device=dev)
@@ -176,7 +178,7 @@ class SAC(Agent):
         x = (obs['obs'] if isinstance(obs, dict) else obs) if z is None else z
         x = x.contiguous()
         rows = x.shape[0]
-        mean, std, lo, hi = self._norm_ptrs()
+        mean, std, lo, hi = self._norm_ptrs() if z is None else (None, None, 0.0, 0.0)   # z is already normalised (sac.py:121-124)
         actions = torch.empty(rows, self.action_dim, dtype=torch.float32, device=self.device)
         logp = torch.empty(rows, dtype=torch.float32, device=self.device) if logprob else None
         noise = self._noise((rows, self.action_dim))

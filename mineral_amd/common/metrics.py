@@ -42,6 +42,7 @@ class Metrics:
             raise _hip.HipLibraryError(f'episode metrics live on the MI355X (device={dev}); no CPU fallback')
         if current_scores['rewards'].dtype != torch.float32 or current_scores['lengths'].dtype != torch.int64:
             raise ValueError('current_scores: rewards float32, lengths int64')
+        _hip.require_current_device(dev)
         self.tracker_len = tracker_len
         rewards = DeviceTracker(tracker_len, dev)
         self.episode_trackers = {'rewards': rewards, 'lengths': DeviceTracker(tracker_len, dev, head=rewards.head)}
@@ -63,7 +64,7 @@ class Metrics:
         if r.numel() != n or d.numel() != n:
             raise ValueError(f'metrics.update: {r.numel()} rewards / {d.numel()} dones for {n} envs')
         t = self.episode_trackers
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = C.c_void_p(torch.cuda.current_stream(cs['rewards'].device).cuda_stream)
         _hip.check(_hip.lib().mrl_episode_update(_hip.ptr(r), _hip.ptr(d), n, _hip.ptr(cs['rewards']), _hip.ptr(cs['lengths']), _hip.ptr(t['rewards'].ring),
                                                  _hip.ptr(t['lengths'].ring), self.tracker_len, _hip.ptr(t['rewards'].head), _hip.ptr(self._num_episodes),
                                                  stream), 'mrl_episode_update')

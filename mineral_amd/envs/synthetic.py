@@ -24,15 +24,22 @@ class SyntheticEnv:
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
         self.counters = torch.arange(self.num_envs, device=self.device) % self.episode_length
-        self._obs = torch.empty(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device)
+        # two observation buffers used in turn: the tensor a step returns stays intact until the step after the next one,
+        # so an agent may still read the previous observation after calling step() (SAC stores obs and next_obs)
+        self._obs2 = [torch.empty(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._flip = 0
         self._rew = torch.empty(self.num_envs, dtype=torch.float32, device=self.device)
 
     def reset(self):
         self.counters = torch.arange(self.num_envs, device=self.device) % self.episode_length
-        return self._obs.normal_(generator=self.gen)
+        return self._next_obs()
+
+    def _next_obs(self):
+        self._flip ^= 1
+        return self._obs2[self._flip].normal_(generator=self.gen)
 
     def step(self, actions):
-        obs = self._obs.normal_(generator=self.gen)
+        obs = self._next_obs()
         rew = self._rew.normal_(generator=self.gen)
         self.counters += 1
         done = self.counters >= self.episode_length

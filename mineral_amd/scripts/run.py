@@ -64,6 +64,8 @@ def prepare(tree):
     else:
         did = tree.get('device_id', 0)
         dev = f'cuda:{did}' if did >= 0 else 'cpu'
+        if did >= 0:
+            torch.cuda.set_device(did)   # the HIP library launches on the current device: it has to be the one that owns the tensors
         tree['graphics_device_id'] = did if did >= 0 else 0
     tree['sim_device'] = dev
     tree['rl_device'] = dev
