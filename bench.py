@@ -99,6 +99,7 @@ def main():
                     help='run the multi-rank code path (process group, collectives) even with one rank: an RCCL rehearsal on a 1-GPU box')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the run at the shipped minibatch_size (2048)')
     args = ap.parse_args()
 
     import torch
@@ -156,22 +157,61 @@ def main():
         one_step()
     if timing:
         torch.cuda.synchronize()
-        L.mrl_profile_enable(2 if args.warmup > 0 else 1)   # timed region: events around the dominant kernel only
+        L.mrl_profile_enable(2)           # fixes the dominant instantiation from the warm-up's timings ...
+        L.mrl_profile_enable(0)           # ... timed region: no events, the product's own launch order
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     fence()
     dt = time.perf_counter() - t0
+    flat64 = agent.model.flat.double()
+    param_checksum = [float(flat64.sum().item()), float((flat64 * flat64).sum().item())]   # run-to-run / rank-count comparisons
+    dominant, dt_events = None, None
+    if timing:
+        # the same K steps once more with HIP events around every launch of the dominant kernel, on the stream it is launched
+        # on.  With events on, the library issues one launch per kernel (both towers) on one stream, so a launch's duration is
+        # its own; the timed region above overlaps the two towers' launch chains on two streams.
+        L.mrl_profile_enable(2 if args.warmup > 0 else 1)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        fence()
+        dt_events = time.perf_counter() - t1
+        if rank == 0:
+            import ctypes as C
+            ms_, n_, flops_ = C.c_double(0), C.c_int64(0), C.c_double(0)
+            name_ = C.create_string_buffer(128)
+            L.mrl_profile_read(C.byref(ms_), C.byref(n_), C.byref(flops_), name_, 128)
+            dominant = (ms_.value, n_.value, flops_.value, name_.value.decode())
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         coll.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # every rank must hold the same parameters after the same number of optimizer steps
         sums = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
-        flat = agent.model.flat.double()
-        coll.all_gather(sums, torch.stack([flat.sum(), (flat * flat).sum()]))
+        coll.all_gather(sums, torch.tensor(param_checksum, dtype=torch.float64, device=dev))
         in_sync = all(bool(torch.equal(sums[0], x)) for x in sums[1:])
+
+    kernel_table = None
+    if timing and rank == 0:
+        # one more update outside the timed region with events around every instantiation: the per-kernel table
+        import ctypes as C
+        L.mrl_profile_enable(1)
+        one_step()
+        torch.cuda.synchronize()
+        text = C.create_string_buffer(16384)
+        n = L.mrl_profile_read_all(text, 16384)
+        kernel_table = []
+        for line in text.value.decode().splitlines()[:12] if n > 0 else []:
+            ms, launches, flops, kname = line.split('\t')
+            ms, launches, flops = float(ms), int(launches), float(flops)
+            kernel_table.append({'name': kname, 'launches': launches, 'avg_us': 1e3 * ms / launches, 'total_ms': ms,
+                                 'tflops': (flops / (ms * 1e-3) / 1e12) if flops > 0 else None})
+        L.mrl_profile_enable(0)
+    elif timing:
+        one_step()   # the other ranks take part in the extra update's collectives
 
     env_steps = args.num_envs * T_HORIZON * world * args.steps
     out = {
@@ -186,29 +226,57 @@ def main():
                    'num_envs_total': args.num_envs * world, 'ms_per_update': 1e3 * dt / args.steps,
                    'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
     }
-    flat64 = agent.model.flat.double()
-    out['param_checksum'] = [float(flat64.sum().item()), float((flat64 * flat64).sum().item())]   # run-to-run / rank-count comparisons
+    out['param_checksum'] = param_checksum
     if multi:
         out['ranks_in_sync'] = in_sync
     if rank == 0:
-        if timing:
-            import ctypes as C
-            ms, n, flops = C.c_double(0), C.c_int64(0), C.c_double(0)
-            name = C.create_string_buffer(128)
-            L.mrl_profile_read(C.byref(ms), C.byref(n), C.byref(flops), name, 128)
+        if timing and dominant is not None:
+            class _V:   # the dominant kernel of the timed region, read before the extra table-gathering update
+                def __init__(self, v):
+                    self.value = v
+            ms, n, flops, kname = _V(dominant[0]), _V(dominant[1]), _V(dominant[2]), dominant[3]
             if n.value > 0:
                 achieved = flops.value / (ms.value * 1e-3) / 1e12
-                kname = name.value.decode()
                 # kernels that multiply exact three-term bf16 splits of the fp32 operands issue six bf16 MFMA terms per
                 # fp32 product: their ceiling for algorithmic (fp32) FLOPs is the dense bf16 peak / 6; the others run the
                 # fp32 MFMA (157.3 TFLOP/s)
-                split = 'split_kernel' in kname or (kname.startswith('mrl::gemm_kernel<') and kname.count(',') == 10 and kname.endswith(', 1>'))
+                split = 'split_kernel' in kname or (kname.startswith('mrl::gemm_kernel<') and kname.count(',') == 10 and (kname.endswith(', 1>') or kname.endswith(', 2>')))
                 peak = 2500.0 / 6.0 if split else 157.3
                 out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                    'traffic': measured_traffic(kname), 'kernel': kname, 'launches': int(n.value),
                                    'avg_launch_us': 1e3 * ms.value / n.value,
                                    'peak_basis': ('dense bf16 MFMA peak 2500 / 6 split terms per fp32 product' if split else 'dense fp32 MFMA peak'),
-                                   'frac_of_fp32_mfma_peak': achieved / 157.3}
+                                   'frac_of_fp32_mfma_peak': achieved / 157.3,
+                                   'measured_over': f'a second pass of the same {args.steps} steps with HIP events around every launch of this kernel '
+                                                    f'(single-stream launch order), {1e3 * dt_events / args.steps:.1f} ms per step'}
+                if kernel_table:
+                    out['roofline']['kernels'] = kernel_table
+        if not args.no_secondary and not multi and args.minibatch != 2048:
+            # the minibatch size the reference ships for this network (cfgs/agent/DFlexAntPPO.yaml: minibatch_size 2048):
+            # 5,120 optimizer steps per update instead of 320, a launch- and latency-bound regime
+            del agent
+            torch.cuda.empty_cache()
+            cfg2 = make_cfg(args.num_envs, 2048, dev, False)
+            cfg2.env_seed = 365838
+            env2 = synthetic.make_envs(cfg2)
+            with contextlib.redirect_stdout(sys.stderr):
+                agent2 = PPO(cfg2, logdir=logdir, accelerator=None, datasets=None, env=env2)
+            agent2.obs = agent2._convert_obs(env2.reset())
+
+            def step2():
+                agent2.epoch += 1
+                agent2.play_steps()
+                agent2.train_epoch()
+            step2()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n2 = max(1, min(2, args.steps))
+            for _ in range(n2):
+                step2()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t2) / n2
+            out['secondary'] = {'minibatch': 2048, 'optimizer_steps_per_update': 5 * args.num_envs * T_HORIZON // 2048, 'updates_timed': n2,
+                                'ms_per_update': 1e3 * dt2, 'value': args.num_envs * T_HORIZON / dt2, 'unit': 'env-steps/s'}
         if not args.no_cpu_baseline and not multi:   # the CPU leg is timed at N=1 only
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

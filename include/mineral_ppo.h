@@ -203,13 +203,18 @@ int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 
 /* Benchmark support, no counterpart in the reference: time the MFMA GEMM launches with HIP events on the stream
  * they are issued to.  mode 0 = off (default), 1 = every GEMM instantiation, 2 = only the instantiation that has
- * accumulated the most time so far (call after a mode-1 warm-up); every call drops the data gathered before.
+ * accumulated the most time so far (call after a mode-1 warm-up; with nothing timed since the last call the choice of the last
+ * mode-2 call stands); every call drops the data gathered before.  While timing is on, mrl_ppo_grad issues its launches in
+ * the single-stream order.
  * mrl_profile_read waits for the recorded events and reports the instantiation with the largest total time:
  * summed duration, launch count, summed algorithmic FLOPs (2*M*N*K per launch) and the kernel's name.
  * Not thread-safe; leave off outside benchmarks. */
 int mrl_profile_enable(int mode);
 int mrl_profile_read(double* total_ms_host, int64_t* launches_host, double* flops_host, char* name_host,
                      int32_t name_len);
+/* The same for every timed instantiation, slowest first, as text: one line "<total ms>\t<launches>\t<flops>\t<name>\n" each.
+ * Returns the number of bytes written (terminating NUL not counted) or a negative status. */
+int mrl_profile_read_all(char* text_host, int32_t text_len);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmineral_ppo.so')
+# MRL_LIB selects another build of the same library (diagnostic builds under tools/bin); the default is the in-tree product
+LIB_PATH = os.environ.get('MRL_LIB') or os.path.join(_HERE, 'libmineral_ppo.so')
 
 MAX_LAYERS = 4
 NMETRIC = 12
@@ -129,6 +130,7 @@ _SIGNATURES = {
     'mrl_critic_mse_grad': (C.c_int, [C.POINTER(CriticNet), _P, _P, _P, C.c_int64, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P]),
     'mrl_lerp_params': (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, _P]),
     'mrl_profile_enable': (C.c_int, [C.c_int]),
+    'mrl_profile_read_all': (C.c_int, [C.c_char_p, C.c_int32]),
     'mrl_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_char_p, C.c_int32]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -16,6 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MRL_ABLATE_FWD
+#define MRL_ABLATE_FWD 0   // diagnostic builds only: bit 0 no activation stores, 1 no split, 2 no operand prologue, 3 one step (split-bf16 forward loop)
+#endif
+
 namespace mrl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -268,8 +272,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   static_assert(NT == 256 || EPI == EPI_LNFWD || EPI == EPI_BIASFWD, "8-wave blocks are built for the forward kernels");
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered LDS tiles");
   static_assert(MM == 0 || (LA == LAY_K && LB == LAY_K && BK == 16 && NT == 256 && EPI != EPI_SLAB), "split main loop: forward tiles, 16 k per step");
+  static_assert(MM >= 0 && MM <= 2, "MM 2: the split main loop with the weights read from planes split beforehand (GemmP::Bpl)");
   // split main loop: per stage three bf16 planes of [BM + BN rows][16 k] (32 B per row), two stages
-  constexpr int LDS_MAIN = MM ? NBUF * 3 * (BM + BN) * 8 : NBUF * C::LDS_TILES;
+  constexpr int LDS_MAIN = MM ? NBUF * 3 * (BM + BN) * 8 : NBUF * C::LDS_TILES;   // floats
   constexpr int LDS_ALL = (LDS_MAIN > C::LDS_EPI) ? LDS_MAIN : C::LDS_EPI;
   __shared__ __attribute__((aligned(16))) float lds[LDS_ALL];
 
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
   };
 
   constexpr int NG = BK / 8;   // k sub-steps per tile
-  if constexpr (MM == 1) {
+  if constexpr (MM >= 1) {
     // Every fp32 operand element is split exactly into three bf16 terms x = h + m + l (split_rne4) and each product is
     // accumulated in fp32 from the six terms hh, hm, mh, mm, hl, lh; the dropped terms are below 2^-23 of |a*b|.  Planes
     // live in LDS as [rows][16 k] bf16 with the two 16-byte halves of a row swapped on every other group of 8 rows (a
@@ -509,12 +514,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "whole chunks per thread");
     char* sl = reinterpret_cast<char*>(lds);
     const int K = kend;                                              // kbeg == 0 in the forward kernels
-    const int nsteps = K / 16;
+    const int nsteps = (MRL_ABLATE_FWD & 8) ? 1 : K / 16;
     const int ca = tid & 3, row0 = tid >> 2;                         // chunk ca of rows row0 + 64 i
     auto r_off = [](int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) * 16); };
     // A (activations, from HBM) is loaded three steps ahead into alternating register sets; the weights and the prologue
     // vectors (L2-resident, every block reads the same) one step ahead into a single set
-    f32x4 sa[2][A_CH], sb[B_CH], spv0, spv1;
+    // MM 2: the weights come as three bf16 planes split beforehand, in k-blocked order (element (n, k) of the [Nv][K] matrix
+    // at (k / 16) * Nv * 16 + n * 16 + k % 16): 16-byte chunks of 8 k go to LDS as they are, chunk (row, half) = thread
+    // (tid >> 1, tid & 1) plus 128 rows per further chunk
+    constexpr bool WPL = MM == 2;
+    constexpr int BP_CH = BN * 2 / NT;
+    static_assert(!WPL || BN * 2 % NT == 0, "whole plane chunks per thread");
+    typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned short* __restrict__ Wpl = p.Bpl[tw];
+    const int rowp = tid >> 1, halfp = tid & 1;
+    f32x4 sa[2][A_CH], sb[WPL ? 1 : B_CH], spv0, spv1;
+    sp_u32x4 sw[WPL ? BP_CH : 1][3];
     auto sp_load = [&](int st, auto SET) {
       constexpr int S = decltype(SET)::value;
       const int k0 = min(st * 16, K - 16) + 4 * ca;                  // steps past the end re-read the last one; never multiplied
@@ -523,8 +538,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     };
     auto sp_load_w = [&](int st) {
       const int k0 = min(st * 16, K - 16) + 4 * ca;
+      if constexpr (WPL) {
+        // k-blocked planes: the [Nv rows][16 k] tile of step st is one contiguous run, thread tid takes its 16-byte chunk tid
+        const int64_t kb = (int64_t)min(st, K / 16 - 1) * Nv * 16 + 8 * halfp;
+#pragma unroll
+        for (int i = 0; i < BP_CH; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            sw[i][pl] = *reinterpret_cast<const sp_u32x4*>(Wpl + pl * p.pl_stride + kb + (int64_t)min(n0 + rowp + 128 * i, Nv - 1) * 16);
+      } else {
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) sb[i] = *reinterpret_cast<const f32x4*>(Bg + (int64_t)min(n0 + row0 + 64 * i, Nv - 1) * p.ldb + k0);
+      }
       if constexpr (PRO_ON_A && PRO_VEC) {
         spv0 = *reinterpret_cast<const f32x4*>(pro0 + k0);
         spv1 = *reinterpret_cast<const f32x4*>(pro1 + k0);
@@ -532,6 +557,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     };
     auto sp_split = [&](const f32x4 x, char* q) {
       split_u32x2 h, m, l;
+      if constexpr (MRL_ABLATE_FWD & 2) {
+        h = split_u32x2{__float_as_uint(x[0]), __float_as_uint(x[1])};
+        m = split_u32x2{__float_as_uint(x[2]), __float_as_uint(x[3])};
+        l = h;
+      } else
       split_rne4(x, h, m, l);
       *reinterpret_cast<split_u32x2*>(q) = h;
       *reinterpret_cast<split_u32x2*>(q + SPLANE) = m;
@@ -544,14 +574,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
         f32x4 v = sa[S][i];
-        if constexpr (PRO_ON_A) v = transform(v);
+        if constexpr (PRO_ON_A && !(MRL_ABLATE_FWD & 4)) v = transform(v);
         sp_split(v, buf + r_off(row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
       }
+      if constexpr (WPL) {
+#pragma unroll
+        for (int i = 0; i < BP_CH; ++i) {
+          const bool ok = n0 + rowp + 128 * i < Nv;                  // weight rows past the valid outputs contribute zeros
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<sp_u32x4*>(buf + pl * SPLANE + r_off(BM + rowp + 128 * i, halfp)) = ok ? sw[i][pl] : sp_u32x4{0u, 0u, 0u, 0u};
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         const bool ok = n0 + row0 + 64 * i < Nv;                    // weight rows past the valid outputs contribute zeros
         sp_split(ok ? sb[i] : zero, buf + r_off(BM + row0 + 64 * i, ca >> 1) + (ca & 1) * 8);
+      }
       }
     };
     int fa_off[TM], fb_off[TN];
@@ -787,7 +827,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 o4 = {ea[im][in][g * 4] * rstd, ea[im][in][g * 4 + 1] * rstd, ea[im][in][g * 4 + 2] * rstd, ea[im][in][g * 4 + 3] * rstd};
-          *reinterpret_cast<f32x4*>(orow + in * 32 + 8 * g) = o4;
+          if (!(MRL_ABLATE_FWD & 1) || o4[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(orow + in * 32 + 8 * g) = o4;
         }
     }
   } else if constexpr (EPI == EPI_LNBWD) {
@@ -1251,12 +1291,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
       if (tid < MRL_NMETRIC) {
         double s = 0.0;
         for (int w = 0; w < NPART; ++w) s += red[w * MRL_NMETRIC + tid];
-        hp.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
+        hp.metric_part[((int64_t)blockIdx.x * 2 + tw + p.tw0) * MRL_NMETRIC + tid] = s;   // slot of the tower's role (single-tower launches)
       }
       if (tid < 32) {
         float s = 0.f;
         for (int w = 0; w < NPART; ++w) s += csum[w * 32 + tid];
-        hp.headb_part[((int64_t)blockIdx.x * 2 + tw) * 32 + tid] = s;
+        hp.headb_part[((int64_t)blockIdx.x * 2 + tw + p.tw0) * 32 + tid] = s;
       }
     }
   }

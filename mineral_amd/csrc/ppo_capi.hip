@@ -9,7 +9,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -207,7 +209,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   w->headb_part = o; o = align64(o + cdiv(rows, 128) * 64);
   w->small = o; o = align64(o + 4096 + 2 * (int64_t)net->obs_dim + 16 * cdiv(rows, 64));
   w->wplane_stride = align64(L.total);
-  w->wplanes = o; o = align64(o + (3 * w->wplane_stride + 1) / 2);
+  w->wplanes = o; o = align64(o + (6 * w->wplane_stride + 1) / 2);   // natural order, then k-blocked order
   w->total = o;
 }
 
@@ -255,17 +257,40 @@ static void prof_clear() {
   }
 }
 
+// Times the launches enqueued on `s` during its lifetime as one sample of class `cls` (when that class is being timed).
+struct ProfScope {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int cls;
+  hipStream_t s;
+  double flops;
+  ProfScope(int cls_, hipStream_t s_, double flops_ = 0) : cls(cls_), s(s_), flops(flops_) {
+    if (g_prof_mode == 1 || (g_prof_mode == 2 && g_prof_only == cls)) {
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, s);
+    }
+  }
+  ~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, s);
+    g_prof[cls].ev.emplace_back(e0, e1);
+    g_prof[cls].flops += flops;
+  }
+};
+// streaming (HBM-bound) kernels worth a line in the per-kernel table
+#define MRL_PROF_STREAM(name, stream) static const int prof_cls__ = prof_register(name); ProfScope prof_scope__(prof_cls__, stream)
+
 extern "C" int mrl_profile_enable(int mode) {
   if (mode < 0 || mode > 2) MRL_FAIL(MRL_EINVAL, "profile mode %d", mode);
   if (mode == 2) {
     int best = -1;
-    double bt = -1;
+    double bt = 0;
     for (size_t i = 0; i < g_prof.size(); ++i) {
       double t = prof_total_ms(g_prof[i]);
       if (t > bt) { bt = t; best = (int)i; }
     }
-    g_prof_only = best;
-    if (best < 0) mode = 1;
+    if (best >= 0) g_prof_only = best;   // nothing timed since the last call: keep the instantiation chosen then
+    if (g_prof_only < 0) mode = 1;
   }
   prof_clear();
   g_prof_mode = mode;
@@ -288,6 +313,25 @@ extern "C" int mrl_profile_read(double* total_ms, int64_t* launches, double* flo
   *flops = g_prof[best].flops;
   if (name && name_len > 0) snprintf(name, name_len, "%s", g_prof[best].name);
   return MRL_OK;
+}
+
+// Every timed instantiation as one line of text each: "<total ms>\t<launches>\t<algorithmic flops>\t<name>\n", slowest first.
+// Returns the number of bytes written (without the terminating NUL) or a negative status.
+extern "C" int mrl_profile_read_all(char* text_host, int32_t text_len) {
+  if (!text_host || text_len < 1) MRL_FAIL(MRL_EINVAL, "NULL / empty output");
+  std::vector<std::pair<double, int>> order;
+  for (size_t i = 0; i < g_prof.size(); ++i)
+    if (!g_prof[i].ev.empty()) order.emplace_back(-prof_total_ms(g_prof[i]), (int)i);
+  std::sort(order.begin(), order.end());
+  int n = 0;
+  text_host[0] = 0;
+  for (auto& o : order) {
+    const ProfClass& c = g_prof[o.second];
+    const int w = snprintf(text_host + n, (size_t)(text_len - n), "%.6f\t%lld\t%.6e\t%s\n", -o.first, (long long)c.ev.size(), c.flops, c.name);
+    if (w < 0 || w >= text_len - n) break;
+    n += w;
+  }
+  return n;
 }
 
 // `resident` > 0 caps the blocks of this launch that share a CU: unused dynamic LDS is requested so that exactly
@@ -465,9 +509,18 @@ static void launch_wgrad(const GemmP& p, const WgradPlan& w, int pro, int towers
   else launch_wgrad_pro<PRO_NONE>(p, w, towers, s);
 }
 
-// The whole parameter vector as three bf16 planes with x = h + m + l exactly (the split of split_bf16.hip.h), element for
-// element: dgrad_split_kernel<true> reads its weight tiles from the planes instead of splitting them in every block.
-__global__ void split_params_kernel(const float* __restrict__ params, int64_t n, unsigned short* __restrict__ planes, int64_t stride) {
+// The whole parameter vector as three bf16 planes with x = h + m + l exactly (the split of split_bf16.hip.h), twice:
+//   natural order (element i of the flat vector at i of each plane): dgrad_split_kernel<true> reads its [K][N] weight tiles
+//   from it instead of splitting them in every block;
+//   k-blocked order for the forward kernels, per weight matrix W[N][K] with K a multiple of 16: element (n, k) at
+//   (k / 16) * N * 16 + n * 16 + k % 16 from the matrix's start, so that the [N rows][16 k] tile of one reduction step is one
+//   contiguous run (the forward main loop stages exactly that tile).  Tensors that are not such matrices keep the natural order.
+struct SplitDesc { int64_t off; int rows, cols; };          // weight matrices to re-block (rows = N, cols = K)
+#define MRL_MAX_SPLITDESC 16
+struct SplitTable { SplitDesc d[MRL_MAX_SPLITDESC]; int n; };
+
+__global__ void split_params_kernel(const float* __restrict__ params, int64_t n, unsigned short* __restrict__ planes, int64_t stride,
+                                    unsigned short* __restrict__ kplanes, const SplitTable tab) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float x = params[i];
@@ -475,14 +528,36 @@ __global__ void split_params_kernel(const float* __restrict__ params, int64_t n,
   const float r1 = x - split_lo(hp);
   const unsigned mp = split_pack2(r1, 0.f);
   const float r2 = r1 - split_lo(mp);
-  planes[i] = (unsigned short)hp;
-  planes[stride + i] = (unsigned short)mp;
-  planes[2 * stride + i] = (unsigned short)split_pack2(r2, 0.f);
+  const unsigned short h = (unsigned short)hp, m = (unsigned short)mp, l = (unsigned short)split_pack2(r2, 0.f);
+  planes[i] = h;
+  planes[stride + i] = m;
+  planes[2 * stride + i] = l;
+  int64_t j = i;
+  for (int q = 0; q < tab.n; ++q) {
+    const int64_t e = i - tab.d[q].off;
+    if (e >= 0 && e < (int64_t)tab.d[q].rows * tab.d[q].cols) {
+      const int row = (int)(e / tab.d[q].cols), k = (int)(e % tab.d[q].cols);
+      j = tab.d[q].off + (int64_t)(k >> 4) * tab.d[q].rows * 16 + (int64_t)row * 16 + (k & 15);
+    }
+  }
+  kplanes[j] = h;
+  kplanes[stride + j] = m;
+  kplanes[2 * stride + j] = l;
 }
 
 static unsigned short* launch_split_params(const ParamLayout& L, const Workspace& W, float* ws, const float* params, hipStream_t s) {
   unsigned short* planes = reinterpret_cast<unsigned short*>(ws + W.wplanes);
-  hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)cdiv(L.total, 256)), dim3(256), 0, s, params, L.total, planes, W.wplane_stride);
+  SplitTable tab;
+  tab.n = 0;
+  int nl = 0;
+  while (nl < MRL_MAX_LAYERS && L.in_dim[nl] > 0) ++nl;
+  for (int tw = 0; tw < L.n_towers; ++tw)
+    for (int l = 0; l < nl; ++l) {
+      const int rows = (int)((L.b[tw][l] - L.W[tw][l]) / L.in_dim[l]);   // at least the layer's outputs (the offset of b is padded to 4)
+      if (L.in_dim[l] % 16 == 0 && tab.n < MRL_MAX_SPLITDESC) tab.d[tab.n++] = SplitDesc{L.W[tw][l], rows, L.in_dim[l]};
+    }
+  hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)cdiv(L.total, 256)), dim3(256), 0, s, params, L.total, planes, W.wplane_stride,
+                     planes + 3 * W.wplane_stride, tab);
   return planes;
 }
 
@@ -490,17 +565,29 @@ static unsigned short* launch_split_params(const ParamLayout& L, const Workspace
 // (fp32 accuracy on the bf16 matrix cores); false = not eligible, the caller launches the fp32 tile.
 static bool lnfwd_split_eligible(int u, int64_t rows, int in) { return rows > MRL_SMALL_M && in % 16 == 0 && in >= 16 && (u == 256 || u == 128); }
 
+// weight planes usable by the 16-byte chunk loads of the split main loop: given for every tower, starting on a multiple of 8
+// elements, rows a multiple of 8 elements long
+static bool planes_usable(const GemmP& p, int towers) {
+  if (p.ldb % 8) return false;
+  for (int z = 0; z < towers; ++z)
+    if (!p.Bpl[z] || (uintptr_t)p.Bpl[z] % 16) return false;
+  return true;
+}
+
 template <int PRO>
 static void launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s) {
   const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
-  if (u == 256) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
+  const bool wpl = planes_usable(p, towers);
+  if (u == 256 && wpl) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 2>(p, grid, s);
+  else if (u == 256) launch_gemm<128, 256, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
+  else if (wpl) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 2>(p, grid, s);
   else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_K, EPI_LNFWD, PRO, 2, 1>(p, grid, s);
 }
 
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
 static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
                               const float* x, int64_t rows, const float* obs_mean, const float* obs_std, float lo, float hi,
-                              int tw0, int towers, hipStream_t s) {
+                              int tw0, int towers, hipStream_t s, const unsigned short* planes = nullptr) {
   for (int l = 0; l < net->n_layers; ++l) {
     GemmP p;
     memset(&p, 0, sizeof(p));
@@ -509,6 +596,7 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       int tw = tw0 + t;
       p.A[t] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
       p.B[t] = params + L.W[tw][l];
+      p.Bpl[t] = (planes && in % 16 == 0) ? planes + 3 * W.wplane_stride + L.W[tw][l] : nullptr;   // the k-blocked planes
       p.pro0[t] = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
       p.pro1[t] = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
       p.out[t] = ws + W.xhat[tw][l];   // plain towers keep the pre-activation z in the same slot
@@ -516,6 +604,7 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
       p.bias[t] = params + L.b[tw][l];
     }
     p.lda = in; p.ldb = in; p.ldo = u;
+    p.pl_stride = W.wplane_stride;
     p.M = (int)rows; p.N = u; p.K = in;
     p.Nt[0] = p.Nt[1] = u; p.Kt[0] = p.Kt[1] = in;
     p.clamp_lo = lo; p.clamp_hi = hi;
@@ -533,7 +622,9 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
     }
     else if (u == 512 && rows > MRL_SMALL_M && in % 16 == 0) {     // first layer of 512 outputs: split-bf16 main loop, single stage
       const dim3 grid((unsigned)cdiv(p.M, 64), 1, towers);
-      if (obs_mean) launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NORM, 1, 1>(p, grid, s);
+      const bool wpl = planes_usable(p, towers);
+      if (obs_mean && wpl) launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NORM, 1, 2>(p, grid, s);
+      else if (obs_mean) launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NORM, 1, 1>(p, grid, s);
       else launch_gemm<64, 512, 16, 1, 4, LAY_K, LAY_K, EPI_LNFWD, PRO_NONE, 1, 1>(p, grid, s);
     }
     else if (obs_mean) MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_NORM, p, towers, s);
@@ -1203,7 +1294,8 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     hipLaunchKernelGGL(rms_to_f32_kernel, dim3((O + 63) / 64), dim3(64), 0, s, obs_rms->mean, obs_rms->var, obs_rms->eps, O, mean_f, std_f);
   }
   const int tw0 = boot ? 1 : 0, towers = boot ? 1 : 2;
-  launch_towers_fwd(net, L, W, ws, params, obs, N, mean_f, std_f, lo, hi, tw0, towers, s);
+  const unsigned short* wpl = (L.has_norm && N > MRL_SMALL_M) ? launch_split_params(L, W, ws, params, s) : nullptr;
+  launch_towers_fwd(net, L, W, ws, params, obs, N, mean_f, std_f, lo, hi, tw0, towers, s, wpl);
 
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -1407,14 +1499,22 @@ extern "C" int mrl_rms_normalize(const mrl_rms* rms, const float* x, float* y, i
 // ws[W.seeds[tw]] ([rows][32], zero padded): dgrad chain with the LayerNorm/SiLU backward of every layer, then (wgrad)
 // the partial weight-gradient slabs of every layer and head, and (input_grad) the gradient with respect to the first
 // layer's input, one [rows][in_dim] matrix per tower.
+// true when the backward of this network on `mb` rows reads its weights from planes split beforehand
+static bool bwd_uses_planes(const mrl_net* net, const ParamLayout& L, int64_t mb) {
+  if (!L.has_norm || mb <= MRL_SMALL_M) return false;
+  for (int l = 0; l + 1 < net->n_layers; ++l)
+    if (ln_bwd_streamed(net->units[l]) && net->units[l + 1] % 16 == 0) return true;
+  return false;
+}
+
+// planes_ready: the caller has already refreshed the weight planes of the workspace on a stream this one is ordered behind
 static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
-                              float* const* input_grad, hipStream_t s) {
+                              float* const* input_grad, hipStream_t s, bool planes_ready = false) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
   const unsigned short* planes = nullptr;             // refreshed here: the caller may have changed the parameters since the forward
-  if (L.has_norm && mb > MRL_SMALL_M)
-    for (int l = 0; l < last && !planes; ++l)
-      if (ln_bwd_streamed(net->units[l]) && net->units[l + 1] % 16 == 0) planes = launch_split_params(L, W, ws, params, s);
+  if (bwd_uses_planes(net, L, mb))
+    planes = planes_ready ? reinterpret_cast<const unsigned short*>(ws + W.wplanes) : launch_split_params(L, W, ws, params, s);
   // ---- dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) --------------------------
   for (int l = last; l >= 0; --l) {
     GemmP p;
@@ -1475,8 +1575,8 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
       a.act_elu = net->tower_kind == TOWER_LAYERNORM_ELU;
       dim3 grid(W.rowblocks[l], towers);
-      if (u == 512) hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a);
+      if (u == 512) { MRL_PROF_STREAM("ln_bwd_kernel<512>", s); hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a); }
+      else { MRL_PROF_STREAM("ln_bwd_kernel<256>", s); hipLaunchKernelGGL(ln_bwd_kernel<256>, grid, dim3(256), 0, s, a); }
     } else {
       // narrow layers (<= 128 wide): the whole row fits one block's accumulators, LayerNorm backward fused
       const dim3 grid((unsigned)cdiv(p.M, 128), 1, towers);
@@ -1568,7 +1668,42 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
   }
   int gx = (int)cdiv(maxcount, 64);
   if (gx > 2048) gx = 2048;
+  MRL_PROF_STREAM("reduce_slabs_kernel", s);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
+}
+
+// A second stream per device for the per-tower launch chains of mrl_ppo_grad (actor on the caller's stream, critic on this
+// one; both at the default priority), with the two events of the fork and the join.  Created on first use, never destroyed.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static SideStream g_side[MRL_MAX_DEVICES];
+static int side_stream(SideStream** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MRL_MAX_DEVICES) MRL_FAIL(MRL_EHIP, "hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+  SideStream& ss = g_side[dev];
+  if (!ss.s) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ss.s) {
+      hipStream_t st = nullptr;
+      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) MRL_FAIL(MRL_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+      if ((e = hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ss.join, hipEventDisableTiming)) != hipSuccess)
+        MRL_FAIL(MRL_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+      ss.s = st;
+    }
+  }
+  *out = &ss;
+  return MRL_OK;
+}
+// Launch structure of mrl_ppo_grad.  false: both towers in every launch (blockIdx.z).  true: one launch chain per tower on
+// two streams, so that the store bursts and epilogues of one tower's kernels run beside the main loops of the other's
+// (bit-identical results; measured 248.7 -> 243.0 ms per full-size update).  Default: two streams for batches above
+// MRL_SMALL_M rows, where every launch fills the chip several times over; MRL_TOWER_STREAMS=0 / 1 in the environment forces
+// one or the other.  While kernel timing is on (mrl_profile_enable) the single-stream order is used.
+static bool tower_streams(int64_t mb) {
+  static const int forced = [] { const char* e = getenv("MRL_TOWER_STREAMS"); return e ? atoi(e) : -1; }();
+  if (g_prof_mode != 0) return false;   // per-kernel timing wants one launch per kernel and nothing running beside it
+  return forced >= 0 ? forced != 0 : mb > MRL_SMALL_M;
 }
 
 extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
@@ -1592,23 +1727,25 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   const int O = net->obs_dim, A = net->act_dim, nl = net->n_layers, last = nl - 1, U = net->units[last];
   const float* x = buf->obs + row0 * O;
 
-  // ---- forward -------------------------------------------------------------------------------------------------
-  launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s);
   double* metric_part = (double*)(ws + W.metric_part);
   const int hblocks = (int)cdiv(mb, 128);
-  {
+  // heads of towers [tw0, tw0 + towers): losses, KL, seeds d loss / d head, mu / sigma write-back, head-bias partials
+  auto launch_heads = [&](int tw0, int towers, hipStream_t st) {
     GemmP p;
     memset(&p, 0, sizeof(p));
-    for (int tw = 0; tw < 2; ++tw) {
-      p.A[tw] = ws + W.xhat[tw][last];
-      p.B[tw] = params + L.Wh[tw];
-      p.pro0[tw] = L.has_norm ? params + L.g[tw][last] : nullptr;
-      p.pro1[tw] = L.has_norm ? params + L.be[tw][last] : nullptr;
-      p.bias[tw] = params + L.bh[tw];
-      p.Nt[tw] = L.head_rows[tw];
-      p.Kt[tw] = U;
-      p.h.seeds[tw] = ws + W.seeds[tw];
+    for (int k = 0; k < towers; ++k) {
+      const int tw = tw0 + k;
+      p.A[k] = ws + W.xhat[tw][last];
+      p.B[k] = params + L.Wh[tw];
+      p.pro0[k] = L.has_norm ? params + L.g[tw][last] : nullptr;
+      p.pro1[k] = L.has_norm ? params + L.be[tw][last] : nullptr;
+      p.bias[k] = params + L.bh[tw];
+      p.Nt[k] = L.head_rows[tw];
+      p.Kt[k] = U;
     }
+    p.tw0 = tw0;
+    p.h.seeds[0] = ws + W.seeds[0];
+    p.h.seeds[1] = ws + W.seeds[1];
     if (net->fixed_sigma) p.h.fixed_logstd = params + L.bh[0] + A;
     p.lda = U; p.ldb = U;
     p.M = (int)mb; p.N = 32; p.K = U;
@@ -1626,14 +1763,32 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
     p.h.smooth_clamp = hp->use_smooth_clamp != 0;
-    if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, 2), s);
-    else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, 2), s);
+    if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, towers), st);
+    else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, towers), st);
+  };
+  // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
+  const bool planes = L.has_norm && mb > MRL_SMALL_M;
+  const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
+  if (tower_streams(mb)) {
+    SideStream* ss = nullptr;
+    if (int rc = side_stream(&ss)) return rc;
+    if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "fork of the tower streams failed");
+    for (int tw = 0; tw < 2; ++tw) {
+      hipStream_t st = tw == 0 ? s : ss->s;
+      launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, st, wpl);
+      launch_heads(tw, 1, st);
+      launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, true, nullptr, st, planes);
+      launch_grad_reduce(net, L, W, ws, grads, tw, 1, hblocks, st);
+    }
+    if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "join of the tower streams failed");
+  } else {
+    launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s, wpl);
+    launch_heads(0, 2, s);
+    launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes);
+    launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   }
   hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
                      hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
-
-  launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s);
-  launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
   return MRL_OK;
 }
@@ -1659,6 +1814,7 @@ extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, 
   a.grad_scale = grad_scale;
   a.adamw = adamw;
   a.nparts = 0;
+  MRL_PROF_STREAM("gradnorm_partial_kernel + adam_kernel", s);
   if (max_norm > 0.f) {
     int64_t np = cdiv(count, 2048);
     a.nparts = (int)(np > 256 ? 256 : np);

@@ -55,9 +55,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base) {
 // planes then take a 192-byte row pitch, with which four consecutive rows still cover all banks).
 // BMT: output rows per tile, 128 (2 x 2 waves) or 256 (4 x 2 waves, 512 threads: a tile of the layer input is then transformed
 // and split once for 256 output rows instead of once per 128, which is where most of this kernel's VALU work goes).
+#ifndef MRL_ABLATE_WGRAD
+#define MRL_ABLATE_WGRAD 0   // diagnostic builds only: bit 0 no slab stores, 1 no prologue / split, 3 one step
+#endif
 template <int PRO, int BNT, int BMT>
 __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
+  constexpr int WABL = MRL_ABLATE_WGRAD;
   static_assert(BNT == 128 || BNT == 64, "column tiles of 128 or 64");
   static_assert(BMT == 128 || (BMT == 256 && BNT == 128), "row tiles of 128, or 256 x 128");
   constexpr int NTH = BMT * 2;                          // threads per block
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
   const int m0 = (j % p.m_tiles) * BMT, n0 = (j / p.m_tiles) * BNT;
   const int kfull = p.Kt[tw] ? p.Kt[tw] : p.K;
   const int kbeg = split * p.ksplit, kend = min(kfull, kbeg + p.ksplit);
-  const int nsteps = (kend - kbeg + BK - 1) / BK;
+  const int nsteps = (WABL & 8) ? 1 : (kend - kbeg + BK - 1) / BK;
   const float* __restrict__ Ag = p.A[tw];
   const float* __restrict__ Bg = p.B[tw];
 
@@ -146,6 +150,11 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
       u32x2 h, m, l;
       const int row = kr + (NTH / A_CPR) * i;
       char* q = buf + row * AROW + c * 8;
+      if constexpr (WABL & 2) {
+        h = u32x2{__float_as_uint(ra[S][i][0]), __float_as_uint(ra[S][i][1])};
+        m = u32x2{__float_as_uint(ra[S][i][2]), __float_as_uint(ra[S][i][3])};
+        l = h;
+      } else
       split4(k + row < kend ? ra[S][i] : zero, h, m, l);
       *reinterpret_cast<u32x2*>(q) = h;
       *reinterpret_cast<u32x2*>(q + APLANE) = m;
@@ -157,8 +166,14 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
       const int row = krb + (NTH / B_CPR) * i;
       char* q = buf + AOPER + row * BROW + cb * 8;
       f32x4 v = rb[S][i];
+      if constexpr (WABL & 2) {
+        h = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
+        m = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])};
+        l = h;
+      } else {
       if constexpr (PRO != PRO_NONE) v = transform(v);
       split4(k + row < kend ? v : zero, h, m, l);
+      }
       *reinterpret_cast<u32x2*>(q) = h;
       *reinterpret_cast<u32x2*>(q + BPLANE) = m;
       *reinterpret_cast<u32x2*>(q + 2 * BPLANE) = l;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col] = acc[i][jn][r];
+        if (!(WABL & 1) || acc[i][jn][r] == 1.2345e-30f) out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col] = acc[i][jn][r];
       }
 }
 
@@ -262,9 +277,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
 // row) and B = that layer's weights ([K][N]).  K must be a multiple of 16; rows past M are computed from clamped loads and
 // not stored.
 // WPL: the weights come from planes split beforehand (GemmP::Bpl) and go to LDS as they are.
+#ifndef MRL_ABLATE_DGRAD
+#define MRL_ABLATE_DGRAD 0   // diagnostic builds only (tools/ablate_dgrad.sh): bit 0 no output stores, 1 no split of A, 2 no MFMAs, 3 one step
+#endif
 template <bool WPL>
 __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
+  constexpr int ABL = MRL_ABLATE_DGRAD;
   constexpr int APLANE = BM * 32;          // [128 rows][16 k] bf16, 32 B per row; the two 16-byte halves of a row swap places
   constexpr int AOPER = 3 * APLANE;        // on every other group of 8 rows, which spreads a quarter-wave's 16-byte reads over all banks
   constexpr int DSTAGE = AOPER + OPER;     // 27,648 B; two stages
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   if (grp >= p.n_groups) return;                       // padding blocks of the last octet of row tiles (whole blocks leave)
   const int m0 = grp * BM, n0 = j * BN;
   const int K = p.Kt[tw] ? p.Kt[tw] : p.K;
-  const int nsteps = K / BK;
+  const int nsteps = (ABL & 8) ? 1 : K / BK;
   const float* __restrict__ Ag = p.A[tw];
   const float* __restrict__ Bg = p.B[tw];
 
@@ -314,6 +333,11 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
     for (int i = 0; i < 2; ++i) {
       u32x2 h, m, l;
       char* qa = buf + a_off(rowa + 64 * i, ca >> 1) + (ca & 1) * 8;
+      if constexpr (ABL & 2) {
+        h = u32x2{__float_as_uint(ra[S][i][0]), __float_as_uint(ra[S][i][1])};
+        m = u32x2{__float_as_uint(ra[S][i][2]), __float_as_uint(ra[S][i][3])};
+        l = h;
+      } else
       split4(ra[S][i], h, m, l);
       *reinterpret_cast<u32x2*>(qa) = h;
       *reinterpret_cast<u32x2*>(qa + APLANE) = m;
@@ -362,6 +386,16 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   auto mfmas = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+    if ((ABL & 4) && p.M > 0) {                         // keep the fragments alive without multiplying
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          acc[i][0][pl] += (float)fra[S][i][pl][0];
+          acc[i][1][pl] += (float)frb[S][i][pl][0];
+        }
+      return;
+    }
 #pragma unroll
     for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -412,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < p.M) out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
+        if ((ABL & 1) ? (row < p.M && acc[i][jn][r] == 1.2345e-30f) : (row < p.M)) out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
       }
 }
 

@@ -604,6 +604,24 @@ def test_one_rank_rccl_group_matches_the_single_process_path():
 
 
 @pytest.mark.gpu
+def test_per_tower_stream_chains_are_bit_identical_to_the_single_stream_launches():
+    """Above 8192 rows mrl_ppo_grad runs the actor and the critic chain on two streams (fork / join by events).  Same kernels,
+    same fixed-order reductions: the parameters after two updates must equal those of the one-stream launch order bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for mode in ('0', '1'):
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '16384',
+               '--no-kernel-timing', '--no-cpu-baseline']
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MRL_TOWER_STREAMS=mode))
+        assert res.returncode == 0, res.stderr[-2000:]
+        sums.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])['param_checksum'])
+    assert sums[0] == sums[1]
+
+
+@pytest.mark.gpu
 def test_launcher_cli_trains_and_writes_the_reference_artifacts(tmp_path):
     """`python -m mineral.scripts.run task=Synthetic ...` (the drop-in launch line) trains for a few epochs on the HIP path
     and leaves the on-disk artefacts of mineral/scripts/run.py:34-41 and ppo.py:416-426."""
