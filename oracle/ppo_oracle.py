@@ -459,8 +459,12 @@ def minibatch_step(params, optim_state, obs_rms, mb, cfg, hp, lr, grad_hook=None
     return obs_rms, mu, sigma, diag
 
 
-def train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, scheduler=None, grad_hook=None, record=None):
+def train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, scheduler=None, grad_hook=None, record=None, optim_lr=None):
     """ppo.py:248-350 — mini_epochs x (B/mb) contiguous minibatches, mu/sigma write-back, KL LR schedule.
+
+    `lr` is the agent's `last_lr`; `optim_lr` is the learning rate the optimizer's param group holds when that differs
+    (right after PPO.load, ppo.py:429-446: the optimizer state is restored, `last_lr` is not checkpointed).  The optimizer
+    steps with its own value until the end of the first mini-epoch, where ppo.py:344-345 copies `last_lr` into it.
 
     `data` is the flattened dict of experience.py:110-121 (keys obs, actions, neglogp, values, returns,
     advantages, mu, sigma); `data['mu']`/`data['sigma']` are overwritten in place as at ppo.py:313.
@@ -470,12 +474,13 @@ def train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, scheduler=None,
     mbs = hp.minibatch_size
     assert B % mbs == 0                                          # ppo.py:83
     results = {}
+    step_lr = lr if optim_lr is None else optim_lr
     for mini_ep in range(hp.mini_epochs):
         kls = []
         for i in range(B // mbs):
             sl = slice(i * mbs, (i + 1) * mbs)                    # experience.py:61-64
             mb = {k: v[sl] for k, v in data.items()}
-            obs_rms, mu, sigma, diag = minibatch_step(params, optim_state, obs_rms, mb, cfg, hp, lr, grad_hook)
+            obs_rms, mu, sigma, diag = minibatch_step(params, optim_state, obs_rms, mb, cfg, hp, step_lr, grad_hook)
             data['mu'][sl] = mu                                   # experience.py:83-87
             data['sigma'][sl] = sigma
             kls.append(diag['kl'])
@@ -488,6 +493,7 @@ def train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, scheduler=None,
         results.setdefault('avg_kl', []).append(float(avg_kl))
         if hp.lr_schedule == 'kl':                                # ppo.py:337-338
             lr = scheduler.update(lr, avg_kl.item())
+        step_lr = lr                                              # ppo.py:344-345
         results.setdefault('lr', []).append(lr)
     return obs_rms, lr, results
 

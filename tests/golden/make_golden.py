@@ -237,16 +237,22 @@ def make_cfg(spec, N, T, mb, mini_epochs, epochs, optim_type, logdir, hp_over=No
 
 
 def run_agent(tag, spec, N, T, mb, mini_epochs, epochs, optim_type, hp_over=None, dump_first_step=False,
-              params_every_epoch=True):
+              params_every_epoch=True, save_ckpt=None, load_ckpt=None):
+    """save_ckpt: after training, write the REFERENCE agent's own checkpoint (PPO.save, ppo.py:416-426) to that path.
+    load_ckpt: load that checkpoint into a fresh reference agent (PPO.load, ppo.py:429-446) before training, as
+    `run=train ckpt=...` does (scripts/run.py:146-148); `epochs` then counts the total including the loaded ones."""
     logdir = f'/tmp/golden_{tag}'
     cfg = make_cfg(spec, N, T, mb, mini_epochs, epochs, optim_type, logdir, hp_over)
     env = synth.GoldenEnv(N, spec['obs'], spec['act'])
     agent = ref_ppo.PPO(cfg, logdir=logdir, accelerator=None, datasets=None, env=env)
+    real_save = agent.save
     agent.save = lambda *a, **k: None
     agent._checkpoint_save = lambda *a, **k: None
     shapes = synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], spec['norm'] is not None, True,
                                        spec['fixed_sigma'])
     agent.model.load_state_dict(synth.make_params(shapes, 5), strict=True)
+    if load_ckpt is not None:
+        agent.load(load_ckpt, ckpt_keys='')
 
     step_counter = [0]
     orig_sample = torch.distributions.Normal.sample
@@ -262,7 +268,7 @@ def run_agent(tag, spec, N, T, mb, mini_epochs, epochs, optim_type, hp_over=None
     def spy_train_epoch():
         e = agent.epoch
         d = agent.storage.data_dict
-        if e == 0:
+        if e == 0 and load_ckpt is None:
             for k in ('values', 'returns', 'advantages', 'neglogp', 'actions', 'mu', 'sigma', 'rewards', 'dones'):
                 out[f'e0_pre_{k}'] = d[k].clone()
             out['e0_pre_obs'] = d['obses']['obs'].clone()
@@ -317,6 +323,8 @@ def run_agent(tag, spec, N, T, mb, mini_epochs, epochs, optim_type, hp_over=None
         torch.distributions.Normal.sample = orig_sample
     out['epochs_run'] = np.int64(agent.epoch + 1)
     out['agent_steps'] = np.int64(agent.agent_steps)
+    if save_ckpt is not None:
+        real_save(save_ckpt)    # tensors, numbers and containers only: loads with torch.load(weights_only=True)
     save(tag, **out)
 
 
@@ -338,6 +346,25 @@ def g8_cartpole():
               dump_first_step=True, params_every_epoch=False)
 
 
+def g8_full():
+    """The DFlexAntPPO network itself ([512, 256, 128], LayerNorm + SiLU, sigma head) through the reference's PPO.train()."""
+    run_agent('g8_train_full_dv3_adamw', NETS['full_dv3'], N=64, T=8, mb=256, mini_epochs=2, epochs=2, optim_type='AdamW',
+              params_every_epoch=False)
+
+
+def g16_checkpoint():
+    """A checkpoint written by the REFERENCE's PPO.save after one epoch, and the reference's own continuation from it (a fresh
+    agent and env, PPO.load, one more epoch).  The product has to load the same file and continue the same way."""
+    mid = dict(NETS['full_dv3'], units=[128, 64, 32], obs=64, act=12)
+    ckpt = os.path.join(HERE, 'g16_reference_checkpoint.pth')
+    run_agent('g16_ckpt_first_epoch', mid, N=64, T=8, mb=128, mini_epochs=2, epochs=1, optim_type='AdamW',
+              params_every_epoch=False, save_ckpt=ckpt)
+    os.remove(os.path.join(HERE, 'g16_ckpt_first_epoch.npz'))     # only the checkpoint and the continuation are fixtures
+    run_agent('g16_ckpt_continued', mid, N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim_type='AdamW',
+              params_every_epoch=False, load_ckpt=ckpt)
+    print(f'g16_reference_checkpoint.pth: {os.path.getsize(ckpt) / 1024:.1f} KiB')
+
+
 # ---- G9 / G10: seeds and schedulers -------------------------------------------------------------------
 def g9_g10():
     seeds = {}
@@ -357,8 +384,10 @@ def g9_g10():
 
 
 if __name__ == '__main__':
-    if os.environ.get('GOLDEN_ONLY') == 'g8_cartpole':      # add one fixture without rewriting the others
-        g8_cartpole()
+    only = os.environ.get('GOLDEN_ONLY')                    # add fixtures without rewriting the others
+    if only:
+        for name in only.split(','):
+            {'g8_cartpole': g8_cartpole, 'g8_full': g8_full, 'g16_checkpoint': g16_checkpoint}[name]()
         sys.exit(0)
     g1_g2()
     g3()
@@ -366,4 +395,6 @@ if __name__ == '__main__':
     g5()
     g6_g8()
     g8_cartpole()
+    g8_full()
+    g16_checkpoint()
     g9_g10()

@@ -409,14 +409,16 @@ def _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, logdir):
                    ppo=ppo)))
 
 
-@pytest.mark.parametrize('fixture,net,optim', [('g8_train_mid_dv3_adamw', 'mid', 'AdamW'), ('g8_train_cartpole_adam', 'cartpole', 'Adam')])
-def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path, fixture, net, optim):
+@pytest.mark.parametrize('fixture,net,optim,mb', [('g8_train_mid_dv3_adamw', 'mid', 'AdamW', 128), ('g8_train_cartpole_adam', 'cartpole', 'Adam', 128),
+                                                  ('g8_train_full_dv3_adamw', 'full', 'AdamW', 256)])
+def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path, fixture, net, optim, mb):
     """PPO.train() of the product on the deterministic env against what the REFERENCE produced: the LayerNorm+SiLU net
-    with a sigma head (fixture g8 mid) and the network of CartpolePPO.yaml (no norm, ELU, state-independent log-std)."""
+    with a sigma head (fixture g8 mid), the network of CartpolePPO.yaml (no norm, ELU, state-independent log-std) and the
+    DFlexAntPPO network itself ([512, 256, 128])."""
     from mineral_amd.agents import PPO
     g = golden(fixture)
     spec = NETS[net]
-    N, T, mb, mini_epochs, epochs = 64, 8, 128, 2, 2
+    N, T, mini_epochs, epochs = 64, 8, 2, 2
     cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, str(tmp_path))
     env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
     agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
@@ -467,6 +469,43 @@ def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path, fixture,
     for n, p in agent.model.named_parameters():
         assert_close(cpu(p), g[f'e{last}_p_{n}'], rtol=2e-3, atol=2e-5, what=f'final {n}')
     assert agent.agent_steps == int(g['agent_steps'])
+
+
+def test_training_continues_from_a_checkpoint_written_by_the_reference(hip, golden, tmp_path):
+    """tests/golden/g16_reference_checkpoint.pth is the reference's own PPO.save output after one epoch (ppo.py:416-426) and
+    g16_ckpt_continued what the reference did after PPO.load of it into a fresh agent (ppo.py:429-446).  The product loads the
+    same file and has to continue the same way: epoch counters, parameters, Adam moments and step, running statistics and the
+    optimizer's learning rate come from the file; last_lr restarts from the configured value like the reference's."""
+    from mineral_amd.agents import PPO
+    g = golden('g16_ckpt_continued')
+    spec = NETS['mid']
+    N, T, mb, mini_epochs, epochs = 64, 8, 128, 2, 2
+    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
+    agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    agent.load(os.path.join(os.path.dirname(__file__), 'golden', 'g16_reference_checkpoint.pth'))
+    assert (agent.epoch, agent.agent_steps, agent.optim_step) == (0, N * T, mini_epochs * (N * T // mb))
+    agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
+    agent.save = lambda *a, **k: None
+    agent._checkpoint_save = lambda *a, **k: None
+    seen = {}
+    orig = agent.train_epoch
+
+    def spy():
+        res = orig()
+        seen['kl'] = cpu(res['avg_kl']).clone()
+        return res
+
+    agent.train_epoch = spy
+    agent.train()
+    assert agent.epoch == 1 and agent.agent_steps == int(g['agent_steps'])
+    assert_close(seen['kl'], g['e1_kl'], rtol=5e-3, atol=2e-6, what='avg_kl after the resume')
+    assert agent.last_lr == float(g['e1_last_lr'])
+    assert cpu(agent.obs_rms['obs'].running_count).item() == float(g['e1_obs_rms_count'])
+    assert_close(cpu(agent.obs_rms['obs'].running_mean), g['e1_obs_rms_mean'], 1e-6, 2e-7)
+    assert_close(cpu(agent.value_rms.running_var), g['e1_value_rms_var'], 1e-4, 1e-6)
+    for n, p in agent.model.named_parameters():
+        assert_close(cpu(p), g[f'e1_p_{n}'], rtol=2e-3, atol=2e-5, what=f'{n} after the resumed epoch')
 
 
 def test_full_size_properties(hip):

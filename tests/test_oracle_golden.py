@@ -158,11 +158,14 @@ TRAIN_CASES = [
     ('g8_train_small_normal_adam', 'small_normal', dict(N=16, T=8, mb=64, mini_epochs=2, epochs=2, optim='Adam')),
     ('g8_train_mid_dv3_adamw', 'mid_dv3', dict(N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim='AdamW')),
     ('g8_train_cartpole_adam', 'cartpole', dict(N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim='Adam')),
+    # the DFlexAntPPO network itself
+    ('g8_train_full_dv3_adamw', 'full_dv3', dict(N=64, T=8, mb=256, mini_epochs=2, epochs=2, optim='AdamW')),
 ]
 
 
-def run_oracle_training(spec, c, on_epoch=None, first_step=None):
-    """The reference's PPO.train() loop (ppo.py:185-199) driven through the oracle on GoldenEnv."""
+def run_oracle_training(spec, c, on_epoch=None, first_step=None, resume=None):
+    """The reference's PPO.train() loop (ppo.py:185-199) driven through the oracle on GoldenEnv.  `resume`: a checkpoint
+    dict in the reference's format (ppo.py:416-426) loaded as PPO.load does before training (ppo.py:429-446)."""
     cfg, params = net_cfg(spec), net_params(spec, 5)
     hp = O.PPOHParams(horizon_len=c['T'], minibatch_size=c['mb'], mini_epochs=c['mini_epochs'],
                       optim_type=c['optim'], reward_scale=0.5)
@@ -173,7 +176,20 @@ def run_oracle_training(spec, c, on_epoch=None, first_step=None):
     sched = O.AdaptiveScheduler(hp.kl_threshold, hp.min_lr, hp.max_lr)
     lr = hp.lr
     step = 0
-    for e in range(c['epochs']):
+    first_epoch, optim_lr = 0, None
+    if resume is not None:
+        names = list(params)
+        for n in names:
+            params[n] = resume['model'][n].clone()
+        for i, n in enumerate(names):
+            st = resume['optim']['state'][i]
+            optim_state['exp_avg'][n], optim_state['exp_avg_sq'][n] = st['exp_avg'].clone(), st['exp_avg_sq'].clone()
+            optim_state['step'] = int(st['step'])
+        obs_rms = {k.split('.', 1)[1]: v.clone() for k, v in resume['obs_rms'].items()}
+        value_rms = {k: v.clone() for k, v in resume['value_rms'].items()}
+        optim_lr = float(resume['optim']['param_groups'][0]['lr'])   # last_lr itself is not in the checkpoint
+        first_epoch = int(resume['epoch']) + 1
+    for e in range(first_epoch, c['epochs']):
         noise = torch.stack([synth.gaussianish((c['N'], spec['act']), 900 + step + t) for t in range(c['T'])])
         step += c['T'] + 1          # the bootstrap forward at ppo.py:169 also draws (and discards) a sample
         data, value_rms, obs = O.play_steps(params, obs_rms, value_rms, env, obs, noise, cfg, hp)
@@ -184,7 +200,8 @@ def run_oracle_training(spec, c, on_epoch=None, first_step=None):
                 if not _seen[0]:
                     _seen[0] = True
                     first_step(diag, {k: v.clone() for k, v in params.items()}, optim_state)
-        obs_rms, lr, res = O.train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, sched, record=rec)
+        obs_rms, lr, res = O.train_epoch(params, optim_state, obs_rms, data, cfg, hp, lr, sched, record=rec, optim_lr=optim_lr)
+        optim_lr = None
         if on_epoch is not None:
             on_epoch(e, pre, data, res, lr, obs_rms, value_rms, params)
     return params
@@ -197,6 +214,8 @@ def test_end_to_end_training(golden, fixture, net, c):
     tol = dict(rtol=2e-5, atol=2e-6)
 
     def first_step(diag, params_after, optim_state):
+        if 's0_g_mu.weight' not in g:
+            return
         # gradients seen by optimizer.step are post-clip (ppo.py:296-300)
         grads = diag['grads']
         clipped, _ = O.clip_grad_norm(list(grads.values()), 0.5)
@@ -233,3 +252,30 @@ def test_end_to_end_training(golden, fixture, net, c):
     run_oracle_training(spec, c, on_epoch, first_step)
     assert int(g['epochs_run']) == c['epochs']
     assert int(g['agent_steps']) == c['epochs'] * c['N'] * c['T']
+
+
+def test_training_continues_from_a_checkpoint_written_by_the_reference(golden):
+    """tests/golden/g16_reference_checkpoint.pth was written by the reference's own PPO.save after one epoch; g16_ckpt_continued
+    holds what the reference did after PPO.load of it into a fresh agent (one more epoch).  The oracle resumes the same way:
+    parameters, both Adam moments and the step count, both running statistics, and the optimizer's learning rate (the
+    agent's last_lr is not checkpointed and restarts from the configured value)."""
+    import os
+    ckpt = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'g16_reference_checkpoint.pth'), map_location='cpu', weights_only=True)
+    assert set(ckpt) == {'epoch', 'mini_epoch', 'agent_steps', 'model', 'optim', 'obs_rms', 'value_rms'}
+    g = golden('g16_ckpt_continued')
+    spec, c = NETS['mid_dv3'], dict(N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim='AdamW')
+    seen = {}
+
+    def on_epoch(e, pre, data, res, lr, obs_rms, value_rms, params):
+        seen['e'] = e
+        n_mb = c['N'] * c['T'] // c['mb']
+        close(np.array(res['kl']).reshape(c['mini_epochs'], n_mb).mean(1), g[f'e{e}_kl'], rtol=1e-3, atol=1e-7)
+        assert lr == float(g[f'e{e}_last_lr'])
+        exact(obs_rms['running_count'], g[f'e{e}_obs_rms_count'])
+        close(obs_rms['running_mean'], g[f'e{e}_obs_rms_mean'], rtol=1e-7, atol=1e-9)
+        close(value_rms['running_var'], g[f'e{e}_value_rms_var'], rtol=1e-6, atol=1e-9)
+        for n, p in params.items():
+            close(p, g[f'e{e}_p_{n}'], rtol=2e-5, atol=2e-6)
+
+    run_oracle_training(spec, c, on_epoch, resume=ckpt)
+    assert seen['e'] == 1 and int(g['epochs_run']) == 2

@@ -79,7 +79,8 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize('O,A,au,cu,B', [(8, 4, [64, 32], [64, 32], 48), (64, 12, [512, 256, 128], [512, 256, 128], 300), (12, 4, [128], [256, 64], 129),
-                                          (64, 12, [512, 256, 128], [512, 256, 128], 8200)])   # above 8,192 rows: the split-bf16 GEMMs, incl. the input gradient through the critic
+                                          (64, 12, [512, 256, 128], [512, 256, 128], 8200),   # above 8,192 rows: the split-bf16 GEMMs, incl. the input gradient through the critic
+                                          (64, 12, [512, 256, 128], [512, 256, 128], 2048)])  # the batch and networks of cfgs/agent/DFlexAntSAC.yaml
 def test_sac_gradients_vs_oracle(O, A, au, cu, B):
     from mineral_amd import _hip
     L = _hip.lib()
@@ -133,7 +134,7 @@ def test_sac_gradients_vs_oracle(O, A, au, cu, B):
     loss = torch.sum(torch.stack([torch.nn.functional.mse_loss(q, target) for q in qs]))
     ref = dict(zip(leaves.keys(), torch.autograd.grad(loss, list(leaves.values()))))
     m = metrics.cpu()
-    assert abs(float(m[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss)))
+    assert abs(float(m[0]) - float(loss.detach())) < 2e-4 * max(1.0, abs(float(loss.detach())))
     assert abs(float(m[1]) - float(target.mean())) < 2e-4 and abs(float(m[3]) - float(target.max())) < 2e-4 and abs(float(m[4]) - float(target.min())) < 2e-4
     got = unpack_grads(gc, offs_c, {k: tuple(v.shape) for k, v in pc.items()})
     for name, r in ref.items():
@@ -264,6 +265,62 @@ def test_sac_agent_training_run_vs_reference(case, tmp_path):
     ckpt = torch.load(os.path.join(str(tmp_path), 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
     assert {'epoch', 'mini_epoch', 'agent_steps', 'obs_rms', 'encoder', 'actor', 'critic', 'encoder_target', 'actor_target', 'critic_target', 'log_alpha'} <= set(ckpt)
     assert 'critics.1.mlp.0.weight' in ckpt['critic'] and 'sigma.bias' in ckpt['actor']
+
+
+def test_sac_agent_at_the_baseline_configuration(tmp_path):
+    """BASELINE configuration 4: SAC on the synthetic env with 4096 envs, the 1M-transition device ring, batch 2048, 8 mini-epochs,
+    n-step 3 and the [512, 256, 128] networks (cfgs/agent/DFlexAntSAC.yaml through `task=Synthetic agent=SyntheticSAC`), two
+    epochs after the warm-up.  With every random draw injected from a counter the run is deterministic: two runs must agree bit for
+    bit (fixed-order reductions, no float atomics), all parameters stay finite, and the ring holds exactly the transitions that
+    were emitted (nstep-1 per env still wait in the FIFO)."""
+    from mineral_amd.agents import SAC
+    from mineral_amd.envs import synthetic
+    from mineral_amd.scripts import compose as C
+    N = 4096
+
+    def run():
+        torch.manual_seed(123)      # the orthogonal initial weights come from torch's global generator
+        tree = C.compose(os.path.join(ROOT, 'mineral_amd', 'cfgs'), ['task=Synthetic', 'agent=SyntheticSAC', f'num_envs={N}', 'agent.print_every=-1',
+                                                                      'agent.ckpt_every=-1', f'logdir={tmp_path}'])
+        tree['sim_device'] = tree['rl_device'] = DEV
+        cfg = C.resolve(tree)
+        cfg.env_seed = 1
+        sac = cfg.agent.sac
+        assert (int(sac.memory_size), int(sac.batch_size), int(sac.mini_epochs), int(sac.nstep)) == (1_000_000, 2048, 8, 3)
+        env = synthetic.make_envs(cfg)
+        agent = SAC(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+        agent._checkpoint_save = lambda *a, **k: None
+        calls = [0]
+
+        def draw(kind, shape):
+            calls[0] += 1
+            g = torch.Generator(device=DEV).manual_seed(1000 + calls[0])
+            return torch.randn(shape, device=DEV, generator=g) if kind == 'n' else torch.rand(shape, device=DEV, generator=g)
+
+        agent.noise_fn = lambda shape: draw('n', shape)
+        agent.rand_fn = lambda shape: draw('u', shape)
+        agent.index_fn = lambda high, n: (draw('u', (n,)) * high).long().clamp_(max=high - 1)
+        agent.obs = agent._convert_obs(env.reset())
+        agent.set_eval()
+        traj, steps = agent.explore_env(env, int(sac.warm_up), random=True)
+        agent.memory.add_to_buffer(traj)
+        emitted = traj[1].shape[0]
+        for _ in range(2):
+            agent.epoch += 1
+            traj, _ = agent.explore_env(env, int(sac.horizon_len), sample=True)
+            agent.memory.add_to_buffer(traj)
+            emitted += traj[1].shape[0]
+            res = agent.update_net(agent.memory)
+        torch.cuda.synchronize()
+        assert emitted == N * (int(sac.warm_up) + 2 * int(sac.horizon_len) - (int(sac.nstep) - 1))
+        assert agent.memory.cur_capacity == min(emitted, int(sac.memory_size))
+        for k, v in res.items():
+            assert torch.isfinite(torch.as_tensor(v).float()).all(), k
+        return torch.cat([agent.actor.flat, agent.critic.flat, agent.critic_target.flat, agent.log_alpha]).cpu()
+
+    a, b = run(), run()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), 'the SAC epoch is deterministic for given draws'
 
 
 def test_launcher_cli_runs_sac(tmp_path):

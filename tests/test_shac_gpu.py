@@ -214,6 +214,49 @@ def test_update_critic_layernorm_elu_vs_reference_run(case):
         assert torch.allclose(v.cpu(), torch.from_numpy(G1[f'{case}_critic.{k}']), rtol=2e-3, atol=2e-4), k
 
 
+def test_update_critic_at_the_baseline_configuration():
+    """BASELINE configuration 5, critic side: the single LayerNorm + ELU critic of cfgs/agent/DFlexAntSHAC.yaml on 8192 envs x 32
+    steps, four 65536-row batches, Adam(betas 0.7 / 0.95), clip 1.0.  TD(lambda) targets bit-exact against the oracle; the loss
+    and the gradient of the first 65536-row batch against the oracle's autograd on the same rows (3e-4 of each tensor's largest
+    entry, like every other gradient test); one full update_critic + target blend stays finite and is bit-reproducible."""
+    from mineral_amd.agents.diffrl import CriticDataset, CriticLearner
+    N, T, O, units, NB, iters = 8192, 32, 64, [64, 64], 4, 16
+    obs = synth.gaussianish((T, N, O), 71)
+    rew, nv = synth.gaussianish((T, N), 72), synth.gaussianish((T, N), 73)
+    done = (synth.lcg_t((T, N), 74) > 0.98).float()
+    targets = targets_hip(rew, done, nv, 0.99, 0.95, 'td-lambda')
+    assert torch.equal(targets.cpu(), S.target_values(rew, done, nv, 0.99, 0.95, 'td-lambda'))
+    targets = targets.to(DEV)
+    d_obs = obs.to(DEV)
+    bs = N * T // NB
+    assert bs == 65536
+
+    def run():
+        c, pc = make_critic_v1(O, units, 65)
+        learner = CriticLearner(c, 'Adam', dict(lr=2e-3, betas=(0.7, 0.95)), critic_iterations=iters, max_grad_norm=1.0, target_critic_alpha=0.2)
+        ds = CriticDataset(bs, {'obs': d_obs}, targets, drop_last=False)
+        assert len(ds) == NB
+        b_obs, b_tgt = ds[0]
+        loss = learner.compute_critic_loss(b_obs, b_tgt)
+        grads = {k: v.cpu().clone() for k, v in c.views_of(learner.grads).items()}
+        res = learner.update_critic(ds)
+        learner.update_target()
+        torch.cuda.synchronize()
+        return pc, float(loss), grads, res, torch.cat([c.flat, learner.critic_target.flat]).cpu()
+
+    pc, loss, grads, res, flat = run()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    # CriticDataset flattens time-major (utils.py:42-43): batch 0 = the first 65536 rows of the [T * N] view
+    ref_loss = S.critic_loss(leaves, obs.reshape(-1, O)[:bs], targets.cpu().reshape(-1)[:bs], units, 1, 'ELU', single=True)
+    ref = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
+    assert abs(loss - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()) + 1e-6
+    for k, g in ref.items():
+        assert (grads[k] - g).abs().max().item() <= 3e-4 * g.abs().max().item() + 1e-7, k
+    assert all(torch.isfinite(torch.stack(v)).all() for v in res.values()) and torch.isfinite(flat).all()
+    assert len(res['value_loss']) == iters
+    assert torch.equal(flat, run()[4]), 'update_critic is deterministic'
+
+
 def test_critic_rejects_unknown_activation():
     from mineral_amd import _hip
     from mineral_amd.agents.diffrl import Critic
