@@ -134,6 +134,21 @@ int mrl_episode_update(const float* rewards, const uint8_t* dones, int64_t num_e
                        int64_t* cur_lengths, double* ring_rewards, double* ring_lengths, int32_t window, int64_t* head,
                        int64_t* num_episodes, void* stream);
 
+/* ActorCritic.act(obs_dict, sample=False) (models.py:112-114): the raw output of the mu head, before the distribution's
+ * transform (no tanh for dreamerv3_normal), mu_out [rows][act_dim].  obs_rms may be NULL (input already normalised, as
+ * when the reference's model is called directly). */
+int mrl_policy_mean(const mrl_net* net, const float* params, const mrl_rms* obs_rms, const float* obs, int64_t rows,
+                    float* mu_out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Metrics._update_infos of one env step for ONE regex-selected per-env scalar and ONE aggregation (metrics.py:76-113):
+ * mode 0 `sum` (cur += x), 1 `min` (cur = fmin(cur, x)), 2 `max` (cur = fmax(cur, x)), 3 `final` (cur[done] = x[done]).
+ * The values of the finished envs (dones != 0, in env order) are appended to `ring` (`window` doubles, the key's Tracker) at
+ * the positions mrl_episode_update gives the same episodes' rewards, and those envs restart at 0 or, with reset_nan != 0,
+ * at NaN (metrics.py:110-113).  `head` is the reward ring's head: it is only read here, so call this BEFORE the
+ * mrl_episode_update of the same step.  cur [num_envs] starts at 0 (sum, final) or NaN (min, max). */
+int mrl_info_track(const float* x, const uint8_t* dones, int64_t num_envs, int32_t mode, int32_t reset_nan, float* cur,
+                   double* ring, int32_t window, const int64_t* head, void* stream);
+
 /* Reward shaping + time-out bootstrap + done flags of one step (ppo.py:153-163, reward_shaper.py:10-15):
  * rewards_tn[t] = r*scale (+ gamma*values_tn[t]*time_outs), dones_tn[t] = dones.  time_outs may be NULL. */
 int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float* rewards, const uint8_t* dones,

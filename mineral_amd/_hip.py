@@ -95,6 +95,8 @@ _SIGNATURES = {
     'mrl_workspace_bytes': (C.c_int64, [C.POINTER(Net), C.c_int64]),
     'mrl_policy_act': (C.c_int, [C.POINTER(Net), _P, C.POINTER(Rms), C.POINTER(Rms), _P, _P, C.c_int32, C.POINTER(Rollout), _P, _P,
                                  _P, C.c_int64, _P]),
+    'mrl_policy_mean': (C.c_int, [C.POINTER(Net), _P, C.POINTER(Rms), _P, C.c_int64, _P, _P, C.c_int64, _P]),
+    'mrl_info_track': (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     'mrl_rollout_write': (C.c_int, [C.POINTER(Rollout), C.c_int32, _P, _P, _P, C.c_double, C.c_double, _P]),
     'mrl_episode_update': (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     'mrl_gae_finish': (C.c_int, [C.POINTER(Rollout), _P, C.c_double, C.c_double, C.POINTER(Rms), _P, _P, C.c_int64, _P]),

@@ -52,7 +52,7 @@ class Agent:
         os.makedirs(self.ckpt_dir, exist_ok=True)
         self.tb_dir = os.path.join(self.logdir, 'tb')
         os.makedirs(self.tb_dir, exist_ok=True)
-        writers = [WandbWriter(), TensorboardWriter(self.tb_dir), JsonlWriter(os.path.join(self.logdir, 'metrics.jsonl'))]
+        writers = [WandbWriter(), TensorboardWriter(self.tb_dir, self.full_cfg.to_container() if hasattr(self.full_cfg, 'to_container') else None), JsonlWriter(os.path.join(self.logdir, 'metrics.jsonl'))]
         self.writer = Writer(writers)
 
         self.print_every = full_cfg.agent.get('print_every', -1)

@@ -143,6 +143,66 @@ class ActorCritic:
                 else:                            # biases, and the fixed log-std (models.py:87-88)
                     v.zero_()
 
+    # ---- inference API of the reference's module (models.py:93-126), outside the training loop -----------------------
+    def _scratch(self, rows):
+        """A one-step rollout buffer + workspace for `rows` samples, kept between calls."""
+        sc = getattr(self, '_act_scratch', None)
+        if sc is None or sc['rows'] != rows:
+            dev, A, O = self.device, self.action_dim, self.obs_dim
+            f32 = dict(dtype=torch.float32, device=dev)
+            t = {k: torch.zeros(rows, 1, A, **f32) for k in ('actions', 'mu', 'sigma')}
+            t['obs'] = torch.zeros(rows, 1, O, **f32)
+            t.update({k: torch.zeros(1, rows, **f32) for k in ('neglogp', 'values', 'rewards')})
+            t['dones'] = torch.zeros(1, rows, dtype=torch.uint8, device=dev)
+            t['flat'] = torch.zeros(4, rows, **f32)
+            c = _hip.Rollout(rows, 1, t['obs'].data_ptr(), t['actions'].data_ptr(), t['mu'].data_ptr(), t['sigma'].data_ptr(),
+                             t['neglogp'].data_ptr(), t['values'].data_ptr(), t['rewards'].data_ptr(), t['dones'].data_ptr(),
+                             t['flat'][0].data_ptr(), t['flat'][1].data_ptr(), t['flat'][2].data_ptr(), t['flat'][3].data_ptr())
+            ws = torch.empty(int(_hip.lib().mrl_workspace_bytes(self.net, rows)), dtype=torch.uint8, device=dev)
+            sc = self._act_scratch = dict(rows=rows, t=t, c=c, ws=ws)
+        return sc
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @torch.no_grad()
+    def act(self, obs_dict, sample=True, noise=None):
+        """models.py:110-126.  `obs_dict['obs']` is what the reference's module receives (already normalised by the agent).
+        sample=False returns the raw output of the mu head (a tensor, not a dict), like the reference.  `noise` (rows, A)
+        injects the standard-normal draw; default torch.randn on the device."""
+        obs = (obs_dict['obs'] if isinstance(obs_dict, dict) else obs_dict).to(self.device, torch.float32).contiguous()
+        rows = obs.shape[0]
+        sc = self._scratch(rows)
+        L = _hip.lib()
+        if not sample:
+            mu = torch.empty(rows, self.action_dim, dtype=torch.float32, device=self.device)
+            _hip.check(L.mrl_policy_mean(self.net, _hip.ptr(self.flat), None, _hip.ptr(obs), rows, _hip.ptr(mu), _hip.ptr(sc['ws']),
+                                         sc['ws'].numel(), self._stream()), 'mrl_policy_mean')
+            return mu
+        if noise is None:
+            noise = torch.randn(rows, self.action_dim, dtype=torch.float32, device=self.device)
+        noise = noise.to(self.device, torch.float32).contiguous()
+        _hip.check(L.mrl_policy_act(self.net, _hip.ptr(self.flat), None, None, _hip.ptr(obs), _hip.ptr(noise), 0, sc['c'], None, None,
+                                    _hip.ptr(sc['ws']), sc['ws'].numel(), self._stream()), 'mrl_policy_act')
+        t = sc['t']
+        mu, sigma = t['mu'][:, 0].clone(), t['sigma'][:, 0].clone()
+        return {'neglogp': t['neglogp'][0].clone(), 'values': t['values'][0].clone().unsqueeze(1), 'actions': t['actions'][:, 0].clone(),
+                'mu': mu, 'sigma': sigma, 'distr': torch.distributions.Normal(mu, sigma)}
+
+    @torch.no_grad()
+    def forward(self, input_dict):
+        """models.py:93-108 as an inference call: values, entropy, mu, sigma (and prev_neglogp when `prev_actions` is given) from
+        the device towers.  No autograd graph is built: the training loop gets its gradients from mrl_ppo_grad."""
+        out = self.act(input_dict, sample=True, noise=torch.zeros(input_dict['obs'].shape[0], self.action_dim, device=self.device))
+        distr = out['distr']
+        res = {'values': out['values'], 'entropy': distr.entropy().sum(dim=-1), 'mu': out['mu'], 'sigma': out['sigma'], 'distr': distr}
+        prev = input_dict.get('prev_actions', None)
+        if prev is not None:
+            res['prev_neglogp'] = torch.squeeze(-distr.log_prob(prev.to(self.device)).sum(dim=-1))
+        return res
+
+    __call__ = forward
+
     def train(self, mode=True):
         self.training = mode
         return self

@@ -38,8 +38,12 @@ class PPO(Agent):
             raise _hip.HipLibraryError(f'the PPO hot path runs on an MI355X only (rl_device={self.device}); no CPU fallback')
         if self.ppo_config.get('dapg', None) is not None:
             raise NotImplementedError('DAPG demonstrations are outside the device PPO path')
-        if list(self.obs_space.keys()) != ['obs']:
-            raise NotImplementedError('dict observations are outside the device PPO path')
+        if 'obs' not in self.obs_space or len(self.obs_space['obs']) != 1:
+            raise NotImplementedError('the device PPO path needs a flat `obs` entry (dict observations through an encoder are outside it)')
+        # further keys of the observation dict are not network inputs (models.py:128-134 reads only `obs` when it is present);
+        # they reach the metrics (info_keys) and are not stored in the rollout
+        self._extra_obs_keys = [k for k in self.obs_space if k != 'obs']
+        self.obs_space = {'obs': self.obs_space['obs']}
         dev = torch.device(self.device)
         _hip.require_current_device(dev)
 
@@ -48,6 +52,10 @@ class PPO(Agent):
         if self.normalize_input:
             if not re.match(self.obs_rms_keys, 'obs'):
                 raise NotImplementedError('obs_rms_keys that exclude `obs`')
+            tracked = [k for k in self._extra_obs_keys if re.match(self.obs_rms_keys, k)]
+            if tracked:
+                raise NotImplementedError(f'running statistics of observation keys that are not network inputs ({tracked}): set '
+                                          "network.obs_rms_keys to '^obs$'")
             self.obs_rms = {'obs': normalizers.RunningMeanStd(self.obs_space['obs'], **rms_config)}
         else:
             self.obs_rms = None
@@ -329,25 +337,32 @@ class PPO(Agent):
 
     # ---------------------------------------------------------------------------------------------------------------
     def eval(self):
-        """ppo.py:352-408: sample actions until 2*N episodes have finished, dump scores.json."""
+        """ppo.py:352-408: sample actions until 2*N episodes have finished, dump scores.json.  The policy steps write a one-step
+        buffer of their own, not the training rollout."""
         self.set_eval()
         obs = self._convert_obs(self.env.reset())
         total = self.num_actors * 2
         eval_metrics = self._create_metrics(total, self.metrics_kwargs)
         old, self.metrics = self.metrics, eval_metrics
-        scratch = torch.zeros(self.num_actors, dtype=torch.float32, device=self.device)
+        old_storage = self.storage
+        self.storage = ExperienceBuffer(self.num_actors, 1, self.num_actors, self.num_actors, self.obs_space, self.action_dim,
+                                        torch.device(self.device), self.cpu_obs_keys)
         try:
             with torch.no_grad():
                 while self.metrics.num_episodes < total:
-                    actions = self.model_act(obs, 0)     # row 0 of the rollout buffer doubles as scratch
+                    if not self.env_autoresets:
+                        raise NotImplementedError      # ppo.py:364-365
+                    actions = self.model_act(obs, 0)
                     obs, r, dones, infos = self.env.step(actions)
                     obs = self._convert_obs(obs)
                     r = torch.as_tensor(r, device=self.device, dtype=torch.float32)
                     self.metrics.update(self.epoch, self.env, obs, r, torch.as_tensor(dones, device=self.device), infos)
+            self.metrics.flush_video(self.epoch)
             metrics = {
                 'eval_scores/num_episodes': self.metrics.num_episodes,
                 'eval_scores/episode_rewards': self.metrics.episode_trackers['rewards'].mean(),
                 'eval_scores/episode_lengths': self.metrics.episode_trackers['lengths'].mean(),
+                **self.metrics.result(prefix='eval'),
             }
             print(metrics)
             self.writer.add(self.agent_steps, metrics)
@@ -359,7 +374,7 @@ class PPO(Agent):
             json.dump(scores, open(os.path.join(self.logdir, 'scores.json'), 'w'), indent=4)
         finally:
             self.metrics = old
-            del scratch
+            self.storage = old_storage
 
     def set_train(self):
         self.model.train()

@@ -24,15 +24,60 @@ class Writer:
         self._metrics.clear()
 
 
-class TensorboardWriter:
-    def __init__(self, tb_dir, config=None):
+class AsyncOutput:
+    """writer.py:24-39: the sink runs on one worker thread; a new batch first waits for the previous one."""
+
+    def __init__(self, callback, parallel=True):
+        self._callback = callback
+        self._parallel = parallel
+        if parallel:
+            import concurrent.futures
+            self._executor = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            self._future = None
+
+    def __call__(self, summaries):
+        if self._parallel:
+            self._future and self._future.result()
+            self._future = self._executor.submit(self._callback, summaries)
+        else:
+            self._callback(summaries)
+
+    def flush(self):
+        if self._parallel and self._future is not None:
+            self._future.result()
+
+
+def flatten_dict(d, prefix='', sep='.'):
+    out = {}
+    for k, v in (d or {}).items():
+        key = f'{prefix}{sep}{k}' if prefix else str(k)
+        if isinstance(v, dict):
+            out.update(flatten_dict(v, key, sep))
+        else:
+            out[key] = v
+    return out
+
+
+class TensorboardWriter(AsyncOutput):
+    """writer.py:42-82: scalars, histograms (1-D), point clouds ((..., 3) with 3 dims), the flattened config as a markdown table
+    under `cfg`.  Without the tensorboard package the sink is a no-op; video summaries (5-D) are refused."""
+
+    def __init__(self, tb_dir, config=None, parallel=True):
+        super().__init__(self._write, parallel)
         try:
             from torch.utils.tensorboard import SummaryWriter
             self.writer = SummaryWriter(tb_dir)
         except Exception:
             self.writer = None
+        if self.writer is not None and config:
+            try:
+                import pandas as pd
+                import tabulate  # noqa: F401  (pandas.to_markdown needs it)
+                self.writer.add_text('cfg', pd.DataFrame.from_dict(flatten_dict(config), orient='index').to_markdown(), 0)
+            except ImportError:
+                pass
 
-    def __call__(self, summaries):
+    def _write(self, summaries):
         if self.writer is None:
             return
         for step, name, value in summaries:
@@ -41,6 +86,10 @@ class TensorboardWriter:
                 self.writer.add_scalar(name, value, step)
             elif value.ndim == 1:
                 self.writer.add_histogram(name, value, step)
+            elif value.ndim == 3 and value.shape[-1] == 3:
+                self.writer.add_mesh(name, value, global_step=step)
+            elif value.ndim == 5:
+                raise NotImplementedError(f'video summary `{name}`: gif encoding (writer.py:84-121) is outside this build')
 
 
 class WandbWriter:

@@ -55,6 +55,7 @@ struct HeadsP {
   float* neglogp_out;        // [M]
   float* value_out;          // [M]
   const float* fixed_logstd; // [A] state-independent log-std parameter (models.py:66-67,151) or null: log-std from the head
+  int raw_mu;                // rollout mode: store only the mu head's raw output (models.py:112-114, act(sample=False)) in `mu`
   const double* vrms_mean;   // value_rms state (fp64) or null when normalize_value is off
   const double* vrms_var;
   float vrms_eps;
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           in_nl[it] = hp.old_neglogp[rowc];
           in_adv[it] = hp.adv[rowc];
         } else {
-          in_a[it] = jv ? hp.noise[(int64_t)rowc * A + j] : 0.f;
+          in_a[it] = (jv && hp.noise) ? hp.noise[(int64_t)rowc * A + j] : 0.f;
           in_mu[it] = in_sg[it] = in_nl[it] = in_adv[it] = 0.f;
         }
       }
@@ -1131,6 +1132,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
             hp.sigma[o_idx] = sigma;
           }
           if (rv && j == 0) hp.neglogp_out[row] = lp;   // the log-probability itself
+        } else if (EPI == EPI_HEADS_ACT && hp.raw_mu) {
+          if (rv && jv) hp.mu[(int64_t)row * hp.out_rs + hp.out_off + j] = o;   // models.py:112-114: mu before the distribution's transform
         } else if constexpr (EPI == EPI_HEADS_ACT) {
           // mineral/agents/ppo/models.py:115-117 with sample = mu + sigma * noise
           const float eps = in_a[it];

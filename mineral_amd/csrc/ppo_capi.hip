@@ -767,6 +767,56 @@ __global__ __launch_bounds__(256) void episode_update_kernel(const float* __rest
   }
 }
 
+// One regex-selected per-env scalar of Metrics._update_infos (metrics.py:76-113) for one aggregation: mode 0 running sum,
+// 1 running minimum, 2 running maximum (NaN = nothing seen yet; fmin / fmax skip it like torch.fmin / torch.fmax), 3 the
+// value at the episode's last step.  Finished envs append their value to the ring in env order, exactly where
+// episode_update_kernel puts the episode's reward (same head, same ranks), and restart at 0 or NaN.  Reads head only.
+__global__ __launch_bounds__(256) void info_track_kernel(const float* __restrict__ x, const uint8_t* __restrict__ dones, int64_t n, int mode,
+                                                         int reset_nan, float* __restrict__ cur, double* __restrict__ ring, int window,
+                                                         const int64_t* __restrict__ head) {
+  constexpr int U = 4;
+  __shared__ int cnt[U][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t start = (int64_t)blockIdx.x * (256 * U);
+  int64_t total, before;
+  count_done(dones, n, start, &total, &before);
+  float val[U];
+  bool d[U];
+  unsigned long long m[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = start + u * 256 + threadIdx.x;
+    const bool valid = i < n;
+    d[u] = valid && dones[i] != 0;
+    float v = 0.f;
+    if (valid) {
+      const float c = cur[i], xi = x[i];
+      v = mode == 0 ? add_rn(c, xi) : mode == 1 ? fminf(c, xi) : mode == 2 ? fmaxf(c, xi) : (d[u] ? xi : c);
+    }
+    val[u] = v;
+    m[u] = __ballot(d[u]);
+    if (lane == 0) cnt[u][wave] = __popcll(m[u]);
+  }
+  __syncthreads();
+  const int64_t L = window, h0 = head[0];
+  const int64_t kept = total < L ? total : L;
+  const float reset = reset_nan ? __builtin_nanf("") : 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = start + u * 256 + threadIdx.x;
+    if (i >= n) continue;
+    if (d[u]) {
+      int64_t k = before + __popcll(m[u] & ((1ull << lane) - 1ull));
+      for (int q = 0; q < u * 4 + wave; ++q) k += cnt[q >> 2][q & 3];
+      const int64_t rank_from_end = total - 1 - k;
+      if (rank_from_end < L) ring[(h0 + kept - 1 - rank_from_end) % L] = (double)val[u];
+      cur[i] = reset;
+    } else {
+      cur[i] = val[u];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void episode_commit_kernel(const uint8_t* __restrict__ dones, int64_t n, int window, int64_t* __restrict__ head,
                                                              int64_t* __restrict__ num_episodes) {
   int64_t total, before;
@@ -1392,6 +1442,64 @@ extern "C" int mrl_episode_update(const float* rewards, const uint8_t* dones, in
                      cur_rewards, cur_lengths, ring_rewards, ring_lengths, window, (const int64_t*)head);
   hipLaunchKernelGGL(episode_commit_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dones, num_envs, window, head, num_episodes);
   MRL_CHECK_LAUNCH("mrl_episode_update");
+  return MRL_OK;
+}
+
+extern "C" int mrl_info_track(const float* x, const uint8_t* dones, int64_t num_envs, int32_t mode, int32_t reset_nan, float* cur, double* ring,
+                              int32_t window, const int64_t* head, void* stream) {
+  if (!x || !dones || !cur || !ring || !head) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (num_envs < 1 || window < 1) MRL_FAIL(MRL_EINVAL, "num_envs %lld, window %d", (long long)num_envs, window);
+  if (mode < 0 || mode > 3) MRL_FAIL(MRL_EINVAL, "mode %d not in 0..3 (sum, min, max, final)", mode);
+  hipLaunchKernelGGL(info_track_kernel, dim3((unsigned)cdiv(num_envs, 1024)), dim3(256), 0, (hipStream_t)stream, x, dones, num_envs, mode, reset_nan,
+                     cur, ring, window, head);
+  MRL_CHECK_LAUNCH("mrl_info_track");
+  return MRL_OK;
+}
+
+extern "C" int mrl_policy_mean(const mrl_net* net, const float* params, const mrl_rms* obs_rms, const float* obs, int64_t rows, float* mu_out,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+  if (check_net(net)) return MRL_EINVAL;
+  if (!params || !obs || !mu_out || !workspace) MRL_FAIL(MRL_EINVAL, "NULL params/obs/mu_out/workspace");
+  if (rows < 1 || rows >= ((int64_t)1 << 31)) MRL_FAIL(MRL_EINVAL, "rows %lld", (long long)rows);
+  if (obs_rms && obs_rms->size != net->obs_dim) MRL_FAIL(MRL_EINVAL, "obs_rms size %d != obs_dim %d", obs_rms->size, net->obs_dim);
+  Workspace W;
+  workspace_layout(net, rows, &W);
+  if (workspace_bytes < W.total * 4) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)W.total * 4);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
+  ParamLayout L;
+  param_layout(net, &L);
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int O = net->obs_dim, A = net->act_dim, last = net->n_layers - 1, U = net->units[last];
+  float *mean_f = nullptr, *std_f = nullptr;
+  float lo = -5.f, hi = 5.f;
+  if (obs_rms) {
+    mean_f = ws + W.small;
+    std_f = mean_f + O;
+    lo = obs_rms->clamp_lo; hi = obs_rms->clamp_hi;
+    hipLaunchKernelGGL(rms_to_f32_kernel, dim3((O + 63) / 64), dim3(64), 0, s, obs_rms->mean, obs_rms->var, obs_rms->eps, O, mean_f, std_f);
+  }
+  const unsigned short* wpl = (L.has_norm && rows > MRL_SMALL_M) ? launch_split_params(L, W, ws, params, s) : nullptr;
+  launch_towers_fwd(net, L, W, ws, params, obs, rows, mean_f, std_f, lo, hi, 0, 1, s, wpl);
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A[0] = ws + W.xhat[0][last];
+  p.B[0] = params + L.Wh[0];
+  p.pro0[0] = L.has_norm ? params + L.g[0][last] : nullptr;
+  p.pro1[0] = L.has_norm ? params + L.be[0][last] : nullptr;
+  p.bias[0] = params + L.bh[0];
+  p.Nt[0] = L.head_rows[0];
+  p.Kt[0] = U;
+  if (net->fixed_sigma) p.h.fixed_logstd = params + L.bh[0] + A;
+  p.lda = U; p.ldb = U;
+  p.M = (int)rows; p.N = 32; p.K = U;
+  fill_heads_common(net, &p.h);
+  p.h.raw_mu = 1;
+  p.h.mu = mu_out;
+  p.h.out_rs = A; p.h.out_off = 0;
+  if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
+  else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
+  MRL_CHECK_LAUNCH("mrl_policy_mean");
   return MRL_OK;
 }
 

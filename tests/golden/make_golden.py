@@ -387,7 +387,7 @@ if __name__ == '__main__':
     only = os.environ.get('GOLDEN_ONLY')                    # add fixtures without rewriting the others
     if only:
         for name in only.split(','):
-            {'g8_cartpole': g8_cartpole, 'g8_full': g8_full, 'g16_checkpoint': g16_checkpoint}[name]()
+            {'g4': g4, 'g8_cartpole': g8_cartpole, 'g8_full': g8_full, 'g16_checkpoint': g16_checkpoint}[name]()
         sys.exit(0)
     g1_g2()
     g3()

@@ -197,3 +197,20 @@ def shac_inputs(case, seed=17):
     done = (lcg_t((T, N), seed + 3, 1.0) + 0.5 < 0.15).float()
     nv = gaussianish((T, N), seed + 4) * 2.0
     return obs, rew, done, nv
+
+
+# ---- Metrics with info keys (shared by make_golden_metrics.py and the tests) ------------------------------------------
+# name: (num_envs, tracker_len, steps, probability that an env finishes on a step)
+METRICS_CASES = {'small': (37, 10, 40, 0.15), 'wide': (3000, 100, 25, 0.1)}
+METRICS_INFO_KEYS = {'sum': 'succ', 'min': 'dist', 'max': 'dist|succ', 'final': 'dist'}
+
+
+def metrics_step(case, t):
+    """Observation dict (`obs` plus two per-env scalars), rewards and done flags of step t."""
+    N = METRICS_CASES[case][0]
+    p = METRICS_CASES[case][3]
+    seed = 5000 + 97 * t + (0 if case == 'small' else 13)
+    obs = {'obs': gaussianish((N, 8), seed), 'succ': (lcg_t((N,), seed + 1) > 0.5).float(), 'dist': gaussianish((N,), seed + 2).abs() + 0.1}
+    r = gaussianish((N,), seed + 3)
+    d = lcg_t((N,), seed + 4) < (0.95 if t == 7 else p)     # one step finishes almost every env at once
+    return obs, r, d

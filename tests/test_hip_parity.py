@@ -622,6 +622,74 @@ def test_device_metrics_window_equals_deque_semantics(N, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('case', sorted(synth.METRICS_CASES))
+def test_info_key_metrics_vs_reference(golden, case):
+    """Metrics with regex-selected info keys (metrics.py:69-113: sum / min / max / final of per-env scalars of the observation
+    dict, appended to a window when the env finishes) on the device against the windows and result() recorded from the
+    reference class (tests/golden/make_golden_metrics.py)."""
+    from mineral_amd.common.metrics import Metrics
+    g = golden('g17_metrics_info_keys')
+    N, L, steps, _ = synth.METRICS_CASES[case]
+    scores = {'rewards': torch.zeros(N, device=DEV), 'lengths': torch.zeros(N, dtype=torch.int64, device=DEV)}
+    m = Metrics(scores, L, info_keys=synth.METRICS_INFO_KEYS)
+    for t in range(steps):
+        obs, r, d = synth.metrics_step(case, t)
+        m.update(0, None, {k: v.to(DEV) for k, v in obs.items()}, r.to(DEV), d.to(DEV), {})
+    assert m.num_episodes == int(g[f'{case}/num_episodes'])
+    names = [k.split('/', 2)[2] for k in g if k.startswith(f'{case}/window/')]
+    assert sorted(names) == sorted(m.episode_trackers), (names, list(m.episode_trackers))
+    for k in names:
+        # fp32 running sums / extrema of the same values in the same order: bit-equal
+        assert m.episode_trackers[k].window == g[f'{case}/window/{k}'].tolist(), k
+    res = m.result(prefix='train')
+    want = {k.split('/', 2)[2]: float(v) for k, v in g.items() if k.startswith(f'{case}/result/')}
+    assert sorted(res) == sorted(want)
+    for k, v in want.items():
+        assert abs(res[k] - v) <= 1e-12 * max(1.0, abs(v)), k
+
+
+@pytest.mark.gpu
+def test_metrics_refuse_what_the_device_path_does_not_aggregate():
+    from mineral_amd.common.metrics import Metrics
+    scores = {'rewards': torch.zeros(4, device=DEV), 'lengths': torch.zeros(4, dtype=torch.int64, device=DEV)}
+    with pytest.raises(NotImplementedError, match='video'):
+        Metrics(scores, 10, save_video_every=5)
+    with pytest.raises(NotImplementedError, match='video'):
+        Metrics(scores, 10, info_keys={'video': 'rgb'})
+    m = Metrics(scores, 10, info_keys={'sum': 'obs'})
+    with pytest.raises(NotImplementedError, match='one value per env'):
+        m.update(0, None, {'obs': torch.zeros(4, 8, device=DEV)}, torch.zeros(4, device=DEV), torch.zeros(4, dtype=torch.bool, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,net,dist', [('full_dv3', 'full', 'dreamerv3_normal'), ('cartpole', 'cartpole', 'normal')])
+def test_actor_critic_act_and_forward_api(hip, golden, tag, net, dist):
+    """ActorCritic.act / forward (models.py:93-126) of the parameter container against the reference module's own outputs
+    (golden g4: act with injected noise, forward with prev_actions), and act(sample=False) against the oracle's raw mu head."""
+    g = golden(f'g4_model_{tag}')
+    spec = NETS[net]
+    params = synth.make_params(synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], spec.get('norm', 'LayerNorm') is not None, True,
+                                                         spec.get('fixed', False)), 3)      # the parameters the fixture was recorded with
+    model = make_model(spec, params, dist)
+    obs, prev, noise = synth.gaussianish((16, spec['obs']), 41), synth.gaussianish((16, spec['act']), 42), synth.gaussianish((16, spec['act']), 43)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    act = model.act({'obs': dev(obs)}, noise=dev(noise))
+    for k in ('actions', 'mu', 'sigma', 'values'):
+        assert_close(cpu(act[k]), g[f'act_{k}'], **tol, what=f'act {k}')
+    assert_close(cpu(act['neglogp']), g['act_neglogp'], rtol=2e-5, atol=1e-4, what='act neglogp')
+    assert act['values'].shape == (16, 1) and isinstance(act['distr'], torch.distributions.Normal)
+    out = model({'obs': dev(obs), 'prev_actions': dev(prev)})
+    for k in ('values', 'mu', 'sigma'):
+        assert_close(cpu(out[k]), g[k], **tol, what=f'forward {k}')
+    assert_close(cpu(out['entropy']), g['entropy'], rtol=2e-5, atol=1e-4, what='entropy')
+    assert_close(cpu(out['prev_neglogp']), g['prev_neglogp'], rtol=5e-5, atol=2e-4, what='prev_neglogp')
+    raw = model.act({'obs': dev(obs)}, sample=False)
+    assert isinstance(raw, torch.Tensor) and raw.shape == (16, spec['act'])
+    mu_raw, _, _ = O.actor_critic_raw(params, obs, oracle_cfg(spec, dist))
+    assert_close(cpu(raw), mu_raw, **tol, what='act(sample=False): mu before the distribution transform')
+
+
+@pytest.mark.gpu
 def test_one_rank_rccl_group_matches_the_single_process_path():
     """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
     issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's
