@@ -48,7 +48,9 @@ extern "C" {
  * mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.
  * tower_kind: one of MRL_TOWER_*.  fixed_sigma != 0: the log-std is a state-independent parameter of act_dim entries
  * (models.py:66-67,151) stored right after the mu bias; otherwise it is a second head beside mu.
- * Limits of this build: units in {32,64,128,256,512}, obs_dim multiple of 4, act_dim <= 16. */
+ * Limits of this build: units in {32,64,128,256,512}, act_dim <= 16, obs_dim a multiple of 4: observation rows and the rows of
+ * the first layer's weights are 16-byte vectors.  Callers with another width pad both with zero columns (the host classes
+ * do: 37 observations of DFlex Ant become rows of 40). */
 typedef struct mrl_net {
   int32_t obs_dim;
   int32_t act_dim;

@@ -20,12 +20,14 @@ class ExperienceBuffer:
         self.num_envs, self.transitions_per_env = int(num_envs), int(horizon_len)
         self.obs_space, self.act_dim = obs_space, int(act_dim)
         self.obs_dim = int(obs_space['obs'][0])
+        self.obs_pad = (self.obs_dim + 3) // 4 * 4      # rows are read as 16-byte vectors: zero columns up to a multiple of 4
         self.batch_size, self.minibatch_size = int(batch_size), int(minibatch_size)
         self.length = self.batch_size // self.minibatch_size
         N, T, O, A, dev = self.num_envs, self.transitions_per_env, self.obs_dim, self.act_dim, self.device
         f32 = dict(dtype=torch.float32, device=dev)
+        self.obs_store = torch.zeros((N, T, self.obs_pad), **f32)     # what the kernels read and write
         self.storage_dict = {
-            'obses': {'obs': torch.zeros((N, T, O), **f32)},
+            'obses': {'obs': self.obs_store[:, :, :O] if self.obs_pad != O else self.obs_store},
             'actions': torch.zeros((N, T, A), **f32),
             'mu': torch.zeros((N, T, A), **f32),
             'sigma': torch.zeros((N, T, A), **f32),
@@ -43,7 +45,7 @@ class ExperienceBuffer:
         self.data_dict = None
         self.last_range = None
         s = self.storage_dict
-        self.c = _hip.Rollout(N, T, s['obses']['obs'].data_ptr(), s['actions'].data_ptr(), s['mu'].data_ptr(),
+        self.c = _hip.Rollout(N, T, self.obs_store.data_ptr(), s['actions'].data_ptr(), s['mu'].data_ptr(),
                               s['sigma'].data_ptr(), s['neglogp'].data_ptr(), s['values'].data_ptr(), s['rewards'].data_ptr(),
                               s['dones'].data_ptr(), self._flat['values'].data_ptr(), self._flat['returns'].data_ptr(),
                               self._flat['advantages'].data_ptr(), self._flat['neglogp'].data_ptr())
@@ -86,7 +88,8 @@ class ExperienceBuffer:
         N, T = self.num_envs, self.transitions_per_env
         s = self.storage_dict
         self.data_dict = {
-            'obses': {'obs': s['obses']['obs'].view(N * T, self.obs_dim)},
+            'obses': {'obs': self.obs_store.view(N * T, self.obs_pad)[:, : self.obs_dim] if self.obs_pad != self.obs_dim
+                      else self.obs_store.view(N * T, self.obs_dim)},
             'actions': s['actions'].view(N * T, self.act_dim),
             'mu': s['mu'].view(N * T, self.act_dim),
             'sigma': s['sigma'].view(N * T, self.act_dim),

@@ -41,6 +41,9 @@ class ActorCritic:
             raise NotImplementedError('unsupported by the MI355X PPO kernels: ' + ', '.join(unsupported))
         self.obs_space, self.action_dim = obs_space, int(action_dim)
         self.obs_dim = int(obs_space['obs'][0])
+        # the kernels read observation rows as 16-byte vectors: rows (and the first layer's weight rows) are padded with zero
+        # columns to a multiple of 4; the tensors exposed under the reference's names keep the true width
+        self.obs_pad = (self.obs_dim + 3) // 4 * 4
         self.units = [int(u) for u in mlp_kwargs.get('units', [512, 256, 128])]
         self.ln_eps = float(mlp_kwargs.get('norm_kwargs', {}).get('eps', 1e-5))
         self.dist_type = dist.get('dist_type', 'normal')
@@ -48,7 +51,7 @@ class ActorCritic:
         self.fixed_sigma, self.separate_value_mlp = bool(fixed_sigma), True
         self.norm_type, self.act_type = kind
         self.device = torch.device(device)
-        self.net = _hip.make_net(self.obs_dim, self.action_dim, self.units, self.dist_type, self.minstd, self.maxstd, self.ln_eps,
+        self.net = _hip.make_net(self.obs_pad, self.action_dim, self.units, self.dist_type, self.minstd, self.maxstd, self.ln_eps,
                                  tower_kind=_hip.TOWER_KINDS[kind], fixed_sigma=self.fixed_sigma)
         L = _hip.lib()
         count = L.mrl_param_count(self.net)
@@ -77,10 +80,11 @@ class ActorCritic:
         v = OrderedDict()
         k = 0
         for tower in ('actor_mlp', 'value_mlp'):
-            in_f = self.obs_dim
+            in_f = self.obs_pad
             for i, u in enumerate(self.units):
                 b = stride * i
-                v[f'{tower}.mlp.{b}.weight'] = flat[offs[k]: offs[k] + u * in_f].view(u, in_f)
+                w = flat[offs[k]: offs[k] + u * in_f].view(u, in_f)
+                v[f'{tower}.mlp.{b}.weight'] = w[:, : self.obs_dim] if (i == 0 and self.obs_pad != self.obs_dim) else w
                 v[f'{tower}.mlp.{b}.bias'] = flat[offs[k + 1]: offs[k + 1] + u]
                 k += 2
                 if has_norm:
@@ -148,7 +152,7 @@ class ActorCritic:
         """A one-step rollout buffer + workspace for `rows` samples, kept between calls."""
         sc = getattr(self, '_act_scratch', None)
         if sc is None or sc['rows'] != rows:
-            dev, A, O = self.device, self.action_dim, self.obs_dim
+            dev, A, O = self.device, self.action_dim, self.obs_pad
             f32 = dict(dtype=torch.float32, device=dev)
             t = {k: torch.zeros(rows, 1, A, **f32) for k in ('actions', 'mu', 'sigma')}
             t['obs'] = torch.zeros(rows, 1, O, **f32)
@@ -170,7 +174,10 @@ class ActorCritic:
         """models.py:110-126.  `obs_dict['obs']` is what the reference's module receives (already normalised by the agent).
         sample=False returns the raw output of the mu head (a tensor, not a dict), like the reference.  `noise` (rows, A)
         injects the standard-normal draw; default torch.randn on the device."""
-        obs = (obs_dict['obs'] if isinstance(obs_dict, dict) else obs_dict).to(self.device, torch.float32).contiguous()
+        obs = (obs_dict['obs'] if isinstance(obs_dict, dict) else obs_dict).to(self.device, torch.float32)
+        if self.obs_pad != self.obs_dim:
+            obs = torch.nn.functional.pad(obs, (0, self.obs_pad - self.obs_dim))
+        obs = obs.contiguous()
         rows = obs.shape[0]
         sc = self._scratch(rows)
         L = _hip.lib()

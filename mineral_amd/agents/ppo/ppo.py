@@ -56,7 +56,7 @@ class PPO(Agent):
             if tracked:
                 raise NotImplementedError(f'running statistics of observation keys that are not network inputs ({tracked}): set '
                                           "network.obs_rms_keys to '^obs$'")
-            self.obs_rms = {'obs': normalizers.RunningMeanStd(self.obs_space['obs'], **rms_config)}
+            self.obs_rms = None   # built after the model: its state is padded like the model's input rows
         else:
             self.obs_rms = None
         self.value_rms = normalizers.RunningMeanStd((1,), **rms_config)
@@ -68,6 +68,8 @@ class PPO(Agent):
         model_kwargs = dict(self.network_config.get('actor_critic_kwargs', {}))
         self.model = ModelCls(self.obs_space, self.action_dim, device=dev, **model_kwargs)
         print(self.model, '\n')
+        if self.normalize_input:
+            self.obs_rms = {'obs': normalizers.RunningMeanStd(self.obs_space['obs'], pad_to=self.model.obs_pad, **rms_config)}
 
         # --- Optim (ppo.py:53-60): Adam / AdamW on the flat parameter vector ---
         optim_kwargs = dict(self.ppo_config.get('optim_kwargs', {}))
@@ -131,11 +133,12 @@ class PPO(Agent):
         # the layout is not monotone in the row count (tile heights and split plans change with it): size for both uses
         ws_bytes = max(int(L.mrl_workspace_bytes(self.model.net, self.num_actors)), int(L.mrl_workspace_bytes(self.model.net, self.minibatch_size)))
         n_mb = max(1, self.batch_size // self.minibatch_size)
-        mom_bytes = n_mb * 1024 * 2 * self.model.obs_dim * 8 + 65536
+        mom_bytes = n_mb * 1024 * 2 * self.model.obs_pad * 8 + 65536
         self._ws = torch.empty(max(ws_bytes, mom_bytes), dtype=torch.uint8, device=dev)
-        A, O = self.action_dim, self.model.obs_dim
+        A, O = self.action_dim, self.model.obs_pad
         self._actions_clamped = torch.empty(self.num_actors, A, dtype=torch.float32, device=dev)
         self._noise = torch.empty(self.num_actors, A, dtype=torch.float32, device=dev)
+        self._obs_padded = torch.zeros(self.num_actors, O, dtype=torch.float32, device=dev) if O != self.model.obs_dim else None
         self._mb_mean = torch.empty(n_mb, O, dtype=torch.float32, device=dev)
         self._mb_var = torch.empty(n_mb, O, dtype=torch.float32, device=dev)
         self._obs_mean_f = torch.empty(O, dtype=torch.float32, device=dev)
@@ -177,6 +180,9 @@ class PPO(Agent):
     def model_act(self, obs_dict, t, last_values=None):
         """ppo.py:125-131 + the buffer writes of ppo.py:146-148, in one launch sequence."""
         obs = obs_dict['obs'] if isinstance(obs_dict, dict) else obs_dict
+        if self.model.obs_pad != self.model.obs_dim:
+            self._obs_padded[:, : self.model.obs_dim].copy_(obs)    # the padding columns stay zero
+            obs = self._obs_padded
         obs = obs.contiguous()
         boot = t == self.horizon_len
         noise = self._draw_noise()    # the reference also draws (and discards) a sample for the bootstrap forward
@@ -273,12 +279,12 @@ class PPO(Agent):
         mb = self.minibatch_size
         buf = self.storage
         net, flat = self.model.net, self.model.flat
-        obs_flat = buf.storage_dict['obses']['obs']
+        obs_flat = buf.obs_store
         count = float(mb)
         if self.normalize_input:
             # the rollout is fixed for the whole epoch, so the batch moments of every minibatch are computed once;
             # only the (sequential) Welford merge happens per step (ppo.py:258-262)
-            _hip.check(L.mrl_batch_moments(_hip.ptr(obs_flat), self.batch_size, self.model.obs_dim, mb, 1, _hip.ptr(self._mb_mean),
+            _hip.check(L.mrl_batch_moments(_hip.ptr(obs_flat), self.batch_size, self.model.obs_pad, mb, 1, _hip.ptr(self._mb_mean),
                                            _hip.ptr(self._mb_var), _hip.ptr(self._ws), self._ws.numel(), s), 'mrl_batch_moments')
             count = self._sync_moments(n_mb)
             obs_rms = self.obs_rms['obs'].c_struct()

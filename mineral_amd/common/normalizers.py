@@ -36,7 +36,7 @@ class RunningMeanStd:
     """
 
     def __init__(self, shape, eps=1e-4, correction=1, with_clamp=False, clamp_range=(-5.0, 5.0), initial_count='eps',
-                 dtype=torch.float64, device='cuda'):
+                 dtype=torch.float64, device='cuda', pad_to=None):
         if dtype != torch.float64:
             raise NotImplementedError('the HIP normaliser keeps fp64 state; got %s' % dtype)
         self.shape = tuple(shape) if not isinstance(shape, int) else (shape,)
@@ -47,17 +47,29 @@ class RunningMeanStd:
         if initial_count == 'eps':
             initial_count = eps
         self.device = torch.device(device)
-        self.running_mean = torch.zeros(self.shape, dtype=dtype, device=self.device)
-        self.running_var = torch.ones(self.shape, dtype=dtype, device=self.device)
+        # `pad_to`: the kernels read feature vectors whose length is a multiple of 4; the state then lives in vectors of that
+        # length (padding features: mean 0, variance 1, and they only ever see zeros) and the reference's names are views
+        self.size = int(pad_to) if pad_to else self.shape[0]
+        if self.size < self.shape[0]:
+            raise ValueError(f'pad_to {pad_to} < {self.shape[0]} features')
+        self._mean_store = torch.zeros(self.size, dtype=dtype, device=self.device)
+        self._var_store = torch.ones(self.size, dtype=dtype, device=self.device)
+        self.running_mean = self._mean_store[: self.shape[0]]
+        self.running_var = self._var_store[: self.shape[0]]
         self.running_count = torch.tensor(float(initial_count), dtype=dtype, device=self.device)
-        self._moments = torch.empty(2, self.shape[0], dtype=torch.float32, device=self.device)
+        self._moments = torch.empty(2, self.size, dtype=torch.float32, device=self.device)
         self._ws = None
+
+    def _padded(self, x):
+        """(rows, features) -> (rows, size) with zero columns appended."""
+        x = x.reshape(-1, self.shape[0])
+        return x.contiguous() if self.size == self.shape[0] else torch.nn.functional.pad(x, (0, self.size - self.shape[0])).contiguous()
 
     # -- C struct view ---------------------------------------------------------------------------------------
     def c_struct(self):
         lo, hi = self.clamp_range if self.with_clamp else (-float('inf'), float('inf'))
-        return _hip.Rms(self.running_mean.data_ptr(), self.running_var.data_ptr(), self.running_count.data_ptr(),
-                        self.shape[0], self.eps, lo, hi)
+        return _hip.Rms(self._mean_store.data_ptr(), self._var_store.data_ptr(), self.running_count.data_ptr(),
+                        self.size, self.eps, lo, hi)
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -67,7 +79,7 @@ class RunningMeanStd:
 
     def update(self, x):
         """normalizers.py:57-63 for x of shape (rows, size)."""
-        x = x.contiguous()
+        x = self._padded(x)
         rows, cols = x.shape
         need = 1024 * 2 * cols * 8 + 65536
         if self._ws is None or self._ws.numel() < need:
@@ -81,12 +93,12 @@ class RunningMeanStd:
                    'mrl_rms_merge')
 
     def _apply(self, x, unnorm):
-        x = x.contiguous()
+        shape = x.shape
+        x = self._padded(x)
         y = torch.empty_like(x)
         st = self.c_struct()
-        rows = x.numel() // self.shape[0]
-        _hip.check(_hip.lib().mrl_rms_normalize(st, _hip.ptr(x), _hip.ptr(y), rows, unnorm, self._stream()), 'mrl_rms_normalize')
-        return y
+        _hip.check(_hip.lib().mrl_rms_normalize(st, _hip.ptr(x), _hip.ptr(y), x.shape[0], unnorm, self._stream()), 'mrl_rms_normalize')
+        return y[:, : self.shape[0]].reshape(shape) if self.size != self.shape[0] else y.reshape(shape)
 
     def normalize(self, x):
         return self._apply(x, 0)

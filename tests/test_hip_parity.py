@@ -234,7 +234,7 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
         'values': synth.gaussianish((B, 1), 207 + seed),
     }
     s = buf.storage_dict
-    s['obses']['obs'].view(B, -1).copy_(data['obs'])
+    s['obses']['obs'].copy_(data['obs'].view(N, T, -1))
     s['actions'].view(B, A).copy_(data['actions'])
     s['mu'].view(B, A).copy_(data['mu'])
     s['sigma'].view(B, A).copy_(data['sigma'])
@@ -506,6 +506,45 @@ def test_training_continues_from_a_checkpoint_written_by_the_reference(hip, gold
     assert_close(cpu(agent.value_rms.running_var), g['e1_value_rms_var'], 1e-4, 1e-6)
     for n, p in agent.model.named_parameters():
         assert_close(cpu(p), g[f'e1_p_{n}'], rtol=2e-3, atol=2e-5, what=f'{n} after the resumed epoch')
+
+
+def test_observation_width_that_is_not_a_multiple_of_4(hip, tmp_path):
+    """DFlex Ant has 37 observations and 8 actions.  The kernels read 16-byte vectors, so the host classes pad observation
+    rows, the first layer's weight rows and the running statistics with zero columns; the tensors under the reference's
+    names keep their true shapes.  One PPO.train() epoch of the product against the oracle's (which works on 37 columns)."""
+    from mineral_amd.agents import PPO
+    from test_oracle_golden import run_oracle_training
+    spec = dict(obs=37, act=8, units=[128, 64])
+    ospec = dict(obs=37, act=8, units=[128, 64], norm='LayerNorm', act_type='SiLU', fixed_sigma=False, dist_type='dreamerv3_normal')
+    N, T, mb, mini_epochs, epochs = 64, 8, 128, 2, 1
+    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    env = synth.GoldenEnv(N, 37, 8, device=DEV)
+    agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    shapes = synth.actor_critic_shapes(37, 8, spec['units'], True, True, False)
+    agent.model.load_state_dict(synth.make_params(shapes, 5))
+    sd = agent.model.state_dict()
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(sh) for _, sh in shapes]
+    assert sd['actor_mlp.mlp.0.weight'].shape == (128, 37) and agent.model.net.obs_dim == 40
+    agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
+    agent.save = lambda *a, **k: None
+    agent._checkpoint_save = lambda *a, **k: None
+    agent.train()
+    want = {}
+
+    def on_epoch(e, pre, data, res, lr, obs_rms, value_rms, params):
+        want.update(params={k: v.clone() for k, v in params.items()}, obs_rms=obs_rms, lr=lr, mu=data['mu'].clone())
+
+    run_oracle_training(ospec, dict(N=N, T=T, mb=mb, mini_epochs=mini_epochs, epochs=epochs, optim='AdamW'), on_epoch)
+    assert agent.last_lr == want['lr']
+    rms = agent.obs_rms['obs']
+    assert rms.running_mean.shape == (37,) and rms.state_dict()['running_var'].shape == (37,)
+    assert_close(cpu(rms.running_mean), want['obs_rms']['running_mean'], 1e-6, 2e-7)
+    assert_close(cpu(rms.running_var), want['obs_rms']['running_var'], 1e-5, 2e-7)
+    assert_close(cpu(agent.storage.storage_dict['mu'].view(-1, 8)), want['mu'], rtol=1e-4, atol=2e-5)
+    for n, p in agent.model.named_parameters():
+        assert_close(cpu(p), want['params'][n], rtol=2e-3, atol=2e-5, what=n)
+    pad = agent.model.flat[: 128 * 40].view(128, 40)[:, 37:]
+    assert float(pad.abs().max()) == 0.0, 'weights of the padding columns stay zero'
 
 
 def test_full_size_properties(hip):

@@ -209,3 +209,27 @@ def test_sharded_path_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, 'ok'), (1, 'ok')], results
+
+
+def test_host_classes_accept_the_dflex_ant_shapes():
+    """obs=37 / act=8 (DFlex Ant): the parameter container, the rollout buffer and the running statistics are built with
+    observation rows padded to 40 columns for the kernels while every tensor under a reference name keeps its shape."""
+    import torch
+    from mineral_amd.agents.ppo.experience import ExperienceBuffer
+    from mineral_amd.agents.ppo.models import ActorCritic
+    m = ActorCritic({'obs': (37,)}, 8, mlp_kwargs=dict(units=[512, 256, 128], norm_type='LayerNorm', act_type='SiLU'), fixed_sigma=False,
+                    actor_dist_kwargs=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0), device='cpu')
+    assert (m.obs_dim, m.obs_pad, m.net.obs_dim) == (37, 40, 40)
+    sd = m.state_dict()
+    assert sd['actor_mlp.mlp.0.weight'].shape == (512, 37) and sd['value_mlp.mlp.0.weight'].shape == (512, 37)
+    assert sum(v.numel() for v in sd.values()) == 2 * (37 * 512 + 512 * 256 + 256 * 128 + 2 * (512 + 256 + 128) + 512 + 256 + 128) + 128 * 17 + 17
+    w = torch.arange(512 * 37, dtype=torch.float32).view(512, 37)
+    sd['actor_mlp.mlp.0.weight'] = w
+    m.load_state_dict(sd)
+    assert torch.equal(m.state_dict()['actor_mlp.mlp.0.weight'], w)
+    assert float(m.flat[: 512 * 40].view(512, 40)[:, 37:].abs().max()) == 0.0
+    buf = ExperienceBuffer(4, 3, 12, 12, {'obs': (37,)}, 8, 'cpu')
+    assert buf.storage_dict['obses']['obs'].shape == (4, 3, 37) and buf.obs_store.shape == (4, 3, 40)
+    buf.storage_dict['obses']['obs'].copy_(torch.ones(4, 3, 37))
+    assert float(buf.obs_store[:, :, 37:].abs().max()) == 0.0
+    assert buf.prepare_training()['obses']['obs'].shape == (12, 37)

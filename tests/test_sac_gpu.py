@@ -156,7 +156,7 @@ def test_sac_gradients_vs_oracle(O, A, au, cu, B):
     shapes = {k: tuple(v.shape) for k, v in with_head(pa).items()}
     got = unpack_grads(ga, offs_a, shapes)
     m = metrics.cpu()
-    assert abs(float(m[0]) - float(aloss)) < 3e-4 * max(1.0, abs(float(aloss)))
+    assert abs(float(m[0]) - float(aloss.detach())) < 3e-4 * max(1.0, abs(float(aloss.detach())))
     ent = -lp.detach()
     assert abs(float(m[2]) - float(ent.mean())) < 3e-4 * max(1.0, abs(float(ent.mean())))
     ll = log_alpha.clone().requires_grad_(True)
