@@ -48,13 +48,10 @@ def make_cfg(num_envs, minibatch, device, multi_gpu, max_steps=10**12):
                    ppo=ppo)))
 
 
-def cpu_baseline(num_envs=16384, minibatch=32768, threads=None):
-    """The CPU oracle (a torch-CPU restatement of the reference, pinned to its golden vectors) on this host's cores:
-    one full PPO iteration on a bounded sample of the same workload."""
+def _cpu_leg(num_envs, minibatch, threads):
     import torch
     from mineral_amd.envs.synthetic import SyntheticEnv
     from oracle import ppo_oracle as O
-    threads = threads or min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     cfg = O.NetConfig(OBS, ACT, UNITS, 'LayerNorm', 'SiLU', False, 'dreamerv3_normal', 0.1, 1.0)
     params = O.init_params(cfg, torch.Generator().manual_seed(0))
@@ -69,9 +66,26 @@ def cpu_baseline(num_envs=16384, minibatch=32768, threads=None):
     data, value_rms, obs = O.play_steps(params, obs_rms, value_rms, env, obs, noise, cfg, hp)
     O.train_epoch(params, st, obs_rms, data, cfg, hp, hp.lr, sched)
     dt = time.perf_counter() - t0
-    return {'value': num_envs * T_HORIZON / dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 PPO iteration, {num_envs} envs x T={T_HORIZON}, minibatch {hp.minibatch_size}, 5 mini-epochs, '
-                      f'torch-CPU oracle, {dt:.1f} s'}
+    return num_envs * T_HORIZON / dt, dt, hp.minibatch_size
+
+
+def cpu_baseline():
+    """The CPU oracle (a torch-CPU restatement of the reference, pinned to its golden vectors) on this host's cores: one full
+    PPO iteration on a bounded sample of the same workload, twice -- on every core this process may use, and on one thread,
+    which is how the reference's launcher runs torch on the CPU (OMP / MKL threads pinned to 1, mineral/scripts/run.py:53-57)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = max(1, min(usable, int(os.environ.get('OMP_NUM_THREADS', usable))))
+    v_all, dt_all, mbs = _cpu_leg(16384, 32768, threads)
+    v_one, dt_one, _ = _cpu_leg(2048, 32768, 1)
+    return {'value': v_all, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+            'cores_machine': os.cpu_count(), 'cores_usable': usable,
+            'sample': f'1 PPO iteration, 16384 envs x T={T_HORIZON}, minibatch {mbs}, 5 mini-epochs, torch-CPU oracle on {threads} threads, {dt_all:.1f} s',
+            'single_thread': {'value': v_one, 'unit': 'env-steps/s', 'cores': 1,
+                              'sample': f'1 PPO iteration, 2048 envs x T={T_HORIZON}, one minibatch of 65536 rows, 5 mini-epochs, 1 thread '
+                                        f'(the reference launcher pins torch to one CPU thread), {dt_one:.1f} s'}}
 
 
 def measured_traffic(kernel):
@@ -193,6 +207,11 @@ def main():
         sums = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
         coll.all_gather(sums, torch.tensor(param_checksum, dtype=torch.float64, device=dev))
         in_sync = all(bool(torch.equal(sums[0], x)) for x in sums[1:])
+        # what the process group itself reports: every rank contributes its rank and its device index
+        ids = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        coll.all_gather(ids, torch.tensor([float(dist.get_rank()), float(local_rank)], dtype=torch.float64, device=dev))
+        ranks_seen = sorted(int(x[0].item()) for x in ids)
+        devices_seen = [int(x[1].item()) for x in ids]
 
     kernel_table = None
     if timing and rank == 0:
@@ -229,6 +248,8 @@ def main():
     out['param_checksum'] = param_checksum
     if multi:
         out['ranks_in_sync'] = in_sync
+        out['rccl'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_seen': ranks_seen,
+                       'devices_seen': devices_seen}
     if rank == 0:
         if timing and dominant is not None:
             class _V:   # the dominant kernel of the timed region, read before the extra table-gathering update

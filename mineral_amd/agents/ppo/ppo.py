@@ -87,7 +87,9 @@ class PPO(Agent):
         if optim_kwargs.get('amsgrad', False):
             raise NotImplementedError('amsgrad')
         P = self.model.param_count
-        self.grads = torch.zeros(P, dtype=torch.float32, device=dev)
+        # the flat gradient, followed by a few floats that ride in its all-reduce when the envs are sharded over ranks
+        self._grads_full = torch.zeros(P + parallel.GRAD_TAIL, dtype=torch.float32, device=dev)
+        self.grads = self._grads_full[:P]
         self.exp_avg = torch.zeros(P, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=dev)
         self.optim_step = 0
@@ -146,6 +148,7 @@ class PPO(Agent):
         self._metrics = torch.zeros(self.mini_epochs * n_mb, _hip.NMETRIC, dtype=torch.float64, device=dev)
         self._gnorm = torch.zeros(self.mini_epochs * n_mb, dtype=torch.float32, device=dev)
         self._adam_scratch = torch.empty(4096, dtype=torch.uint8, device=dev)
+        self._moment_count = None
         self.noise_fn = None   # tests inject `noise_fn(step_index, shape) -> tensor`; default torch.randn on device
         self._noise_calls = 0
 
@@ -217,10 +220,21 @@ class PPO(Agent):
             self.metrics.update(self.epoch, self.env, self.obs, r, self.dones, infos)
         self.metrics.flush_video(self.epoch)
         self.model_act(self.obs, self.horizon_len, last_values=self.storage.last_values)   # ppo.py:169-170
+        exchange = None
+        self._moment_count = None
+        if self._dist is not None:
+            # sharded envs: the rollout is complete, so the batch moments of this rank's rows of every minibatch can be taken
+            # now and travel together with the GAE sums -- one exchange per update besides the gradient all-reduces
+            if self.normalize_input:
+                self._batch_moments()
+
+            def exchange(sums):
+                self._moment_count = parallel.exchange_update_statistics(
+                    sums, self._mb_mean if self.normalize_input else None, self._mb_var if self.normalize_input else None,
+                    self.minibatch_size, self._dist, self.rank_size)
         self.storage.compute_return(self.storage.last_values, self.gamma, self.tau,
                                     self.value_rms if self.normalize_value else None,     # ppo.py:172-183
-                                    all_reduce=self._dist.all_reduce if self._dist is not None else None,
-                                    world_size=self.rank_size)
+                                    all_reduce=exchange, world_size=self.rank_size)
         self.storage.prepare_training()
 
     def train(self):
@@ -266,11 +280,12 @@ class PPO(Agent):
                   f'last_sps {timings["lastrate"]:.2f},', f'SPS {timings["totalrate"]:.2f} |')
 
     # ---------------------------------------------------------------------------------------------------------------
-    def _sync_moments(self, n_mb):
-        """Combine per-rank minibatch moments (equal counts) so every rank merges identical statistics."""
-        if self._dist is None:
-            return float(self.minibatch_size)
-        return parallel.combine_moments(self._mb_mean, self._mb_var, self.minibatch_size, self._dist, self.rank_size)
+    def _batch_moments(self):
+        """Batch mean / unbiased variance of the observations of every minibatch of the finished rollout (ppo.py:258-262 takes
+        them per minibatch; the rollout does not change during the update, so they are computed once)."""
+        _hip.check(_hip.lib().mrl_batch_moments(_hip.ptr(self.storage.obs_store), self.batch_size, self.model.obs_pad, self.minibatch_size, 1,
+                                                _hip.ptr(self._mb_mean), _hip.ptr(self._mb_var), _hip.ptr(self._ws), self._ws.numel(),
+                                                self._stream()), 'mrl_batch_moments')
 
     def train_epoch(self):
         L = _hip.lib()
@@ -279,14 +294,15 @@ class PPO(Agent):
         mb = self.minibatch_size
         buf = self.storage
         net, flat = self.model.net, self.model.flat
-        obs_flat = buf.obs_store
+        P = flat.numel()
         count = float(mb)
         if self.normalize_input:
-            # the rollout is fixed for the whole epoch, so the batch moments of every minibatch are computed once;
-            # only the (sequential) Welford merge happens per step (ppo.py:258-262)
-            _hip.check(L.mrl_batch_moments(_hip.ptr(obs_flat), self.batch_size, self.model.obs_pad, mb, 1, _hip.ptr(self._mb_mean),
-                                           _hip.ptr(self._mb_var), _hip.ptr(self._ws), self._ws.numel(), s), 'mrl_batch_moments')
-            count = self._sync_moments(n_mb)
+            # only the (sequential) Welford merge happens per step; with sharded envs the moments were taken and merged over the
+            # ranks at the end of play_steps
+            if self._dist is None or self._moment_count is None:
+                self._batch_moments()
+            else:
+                count = self._moment_count
             obs_rms = self.obs_rms['obs'].c_struct()
             lo, hi = obs_rms.clamp_lo, obs_rms.clamp_hi
         else:
@@ -309,17 +325,21 @@ class PPO(Agent):
                                           _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(), s),
                            'mrl_ppo_grad')
                 if self._dist is not None:
-                    parallel.average_gradients(self.grads, self._dist)   # the one collective per optimizer step (ppo.py:292)
+                    # the one collective per optimizer step (ppo.py:292); on the last step of a mini-epoch the sum of the
+                    # mini-epoch's KL values rides in the tail (the reference gathers its metrics every step, ppo.py:305-311)
+                    if i == n_mb - 1:
+                        parallel.pack_scalar(self._grads_full[P:], self._metrics[k0:k + 1, 3].sum())
+                    parallel.average_gradients(self._grads_full, self._dist)
                 self.optim_step += 1
                 _hip.check(L.mrl_adam_step(_hip.ptr(flat), _hip.ptr(self.grads), _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq),
                                            flat.numel(), self._optim_lr, self.betas[0], self.betas[1], self.adam_eps,
                                            self.weight_decay, adamw, self.optim_step, max_norm, grad_scale,
                                            _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_adam_step')
                 k += 1
-            kl = self._metrics[k0:k, 3].mean()
             if self._dist is not None:
-                self._dist.all_reduce(kl)
-                kl = kl / self.rank_size
+                kl = parallel.unpack_scalar(self._grads_full[P:]) / (n_mb * self.rank_size)
+            else:
+                kl = self._metrics[k0:k, 3].mean()
             avg_kls.append(kl)
             if self.lr_schedule == 'kl':                                   # ppo.py:337-338 (one host sync per mini-epoch)
                 self.last_lr = self.scheduler.update(self.last_lr, kl.item())

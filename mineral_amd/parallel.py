@@ -71,3 +71,49 @@ def average_gradients(flat_grads, dist):
     the clip+Adam kernel as `grad_scale`)."""
     dist.all_reduce(flat_grads)
     return flat_grads
+
+
+def exchange_update_statistics(sums, mean, var, count, dist, world_size):
+    """The ONE statistics exchange of a PPO update (besides the gradient all-reduces): every rank contributes the six fp64
+    sums of its GAE scan (advantage / value / return sums and sums of squares) and, when observations are normalised, the
+    batch moments of each of its minibatches, in one all_gather; each rank then combines the W contributions in rank order,
+    so all ranks hold the same bits.  `sums` (6,) fp64 is overwritten with the totals; `mean` / `var` (fp32, (n_mb, features),
+    unbiased variance over `count` rows, or None) with the moments of the union of the ranks' rows.  Returns the merged row
+    count per minibatch."""
+    parts = [sums.reshape(-1)]
+    if mean is not None:
+        parts += [mean.double().reshape(-1), var.double().reshape(-1)]
+    pack = torch.cat(parts)
+    got = [torch.empty_like(pack) for _ in range(world_size)]
+    dist.all_gather(got, pack)
+    total = got[0][:6].clone()
+    for g in got[1:]:
+        total += g[:6]
+    sums.copy_(total.view_as(sums))
+    if mean is None:
+        return float(count)
+    n, k = float(count), mean.numel()
+    gm = [g[6:6 + k].view_as(mean) for g in got]
+    gv = [g[6 + k:6 + 2 * k].view_as(var) for g in got]
+    gmean = torch.stack(gm).mean(0)
+    m2 = torch.zeros_like(gmean)
+    for m, v in zip(gm, gv):
+        m2 += v * (n - 1.0) + n * (m - gmean) ** 2
+    mean.copy_(gmean.float())
+    var.copy_((m2 / (n * world_size - 1.0)).float())
+    return n * world_size
+
+
+GRAD_TAIL = 4   # floats behind the flat gradient that ride in its all-reduce
+
+
+def pack_scalar(tail, value64):
+    """Store an fp64 device scalar in two fp32 slots of the gradient's tail (value = hi + lo), so that it is summed over ranks
+    by the gradient's own fp32 all-reduce: exact to 48 bits with one rank, to fp32 rounding of the sum with several."""
+    hi = value64.float()
+    tail[0] = hi
+    tail[1] = (value64 - hi.double()).float()
+
+
+def unpack_scalar(tail):
+    return tail[0].double() + tail[1].double()

@@ -33,6 +33,14 @@ def dev(t):
     return t.to(DEV).contiguous()
 
 
+def _free_port():
+    """A TCP port the kernel hands out as free right now (for the rendezvous of a subprocess group)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def cpu(t):
     torch.cuda.synchronize()
     return t.detach().cpu()
@@ -614,13 +622,14 @@ def test_two_ranks_share_one_gpu_through_host_staged_gloo():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--backend', 'gloo',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--backend', 'gloo',
            '--num-envs', '1024', '--minibatch', '4096', '--no-kernel-timing']
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['ranks_in_sync'] is True
+    assert out['rccl'] == {'backend': 'gloo', 'world_size': 2, 'ranks_seen': [0, 1], 'devices_seen': [0, 0]}
     assert out['value'] > 0
 
 
@@ -741,7 +750,7 @@ def test_one_rank_rccl_group_matches_the_single_process_path():
     for extra in ([], ['--force-dist']):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '4096',
                '--no-kernel-timing', '--no-cpu-baseline'] + extra
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]))

@@ -161,6 +161,24 @@ def _rank_main(rank, world, port, q):
         dist.all_gather(both, var)
         assert torch.equal(both[0], both[1])
 
+        # (1b) the fused per-update exchange: GAE sums and minibatch moments in one all_gather, KL in the gradient's tail
+        sums = torch.arange(6, dtype=torch.float64) * (rank + 1) + 0.25
+        mean2, var2 = mine.mean(1).float(), mine.var(1, correction=1).float()
+        cnt = parallel.exchange_update_statistics(sums, mean2, var2, mb, dist, world)
+        assert cnt == world * mb and torch.equal(sums, torch.arange(6, dtype=torch.float64) * 3 + 0.5)
+        assert torch.equal(mean2, mean) and torch.equal(var2, var), 'same merge as combine_moments, bit for bit'
+        only = torch.ones(6, dtype=torch.float64) * (rank + 2)
+        assert parallel.exchange_update_statistics(only, None, None, mb, dist, world) == mb and float(only[0]) == 5.0
+        grads = torch.full((10 + parallel.GRAD_TAIL,), float(rank + 1))
+        kl = torch.tensor(0.1234567890123456 * (rank + 1), dtype=torch.float64)
+        parallel.pack_scalar(grads[10:], kl)
+        parallel.average_gradients(grads, dist)
+        assert torch.equal(grads[:10], torch.full((10,), 3.0))
+        assert abs(float(parallel.unpack_scalar(grads[10:])) - 0.1234567890123456 * 3) < 1e-7      # an fp32 sum over the ranks
+        one = torch.zeros(parallel.GRAD_TAIL)
+        parallel.pack_scalar(one, kl)
+        assert abs(float(parallel.unpack_scalar(one)) - float(kl)) < 1e-14                               # exact enough to be invisible with one rank
+
         # (2) one optimizer step: shard-local gradients, summed over ranks and scaled by 1/W, equal the gradient of the
         # union minibatch (the DDP all-reduce of mineral/agents/ppo/ppo.py:292)
         spec = dict(obs=8, act=3, units=[16, 8])
@@ -201,7 +219,10 @@ def _rank_main(rank, world, port, q):
 def test_sharded_path_world_size_2_gloo():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
