@@ -738,6 +738,86 @@ def test_actor_critic_act_and_forward_api(hip, golden, tag, net, dist):
 
 
 @pytest.mark.gpu
+def test_torch_custom_operators_run_the_same_kernels(hip):
+    """torch.ops.mineral.* (mineral_amd/ops.py: torch.library registrations over the C ABI) against the direct calls: GAE +
+    normalisation, one minibatch gradient, clip + AdamW, the running-statistics merge and normalize: identical bits."""
+    import mineral_amd.ops  # noqa: F401  (registers the operators)
+    from mineral_amd.common.normalizers import RunningMeanStd
+    M = torch.ops.mineral
+    spec = NETS['mid']
+    N, T, mb = 64, 8, 256
+    net_i, net_f = [spec['obs'], spec['act'], 1, 0, 0] + spec['units'], [0.1, 1.0, 1e-5]
+    params = oracle_params(spec, 9)
+    model = make_model(spec, params)
+    assert M.param_count(net_i, net_f) == model.param_count
+    L = hip.lib()
+
+    def rollout_args(buf):
+        s = buf.storage_dict
+        flat = torch.stack([buf._flat[k] for k in ('values', 'returns', 'advantages', 'neglogp')])
+        return (buf.obs_store, s['actions'], s['mu'], s['sigma'], s['neglogp'], s['values'], s['rewards'], s['dones'], flat), flat
+
+    # --- GAE + value normalisation
+    bufs = [make_buffer(spec, N, T, mb) for _ in range(2)]
+    for b in bufs:
+        s = b.storage_dict
+        s['rewards'].copy_(synth.gaussianish((T, N, 1), 11)); s['values'].copy_(synth.gaussianish((T, N, 1), 12))
+        s['dones'].copy_((synth.lcg_t((T, N), 14) > 0.8).to(torch.uint8)); s['neglogp'].copy_(synth.gaussianish((T, N), 13))
+    last = dev(synth.gaussianish((N,), 18))
+    vr = [RunningMeanStd((1,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV) for _ in range(2)]
+    bufs[0].compute_return(last, 0.99, 0.95, vr[0])
+    args, flat = rollout_args(bufs[1])
+    stats = torch.zeros(8, device=DEV)
+    ws_g = torch.empty(8192, dtype=torch.uint8, device=DEV)
+    M.gae_finish(*args, last, 0.99, 0.95, vr[1].running_mean, vr[1].running_var, vr[1].running_count, 1e-5, -5.0, 5.0, stats, ws_g)
+    for i, k in enumerate(('values', 'returns', 'advantages', 'neglogp')):
+        assert torch.equal(flat[i], bufs[0]._flat[k]), k
+    assert torch.equal(vr[0].running_var, vr[1].running_var) and torch.equal(vr[0].running_count, vr[1].running_count)
+
+    # --- one minibatch gradient + clip + AdamW
+    outs = []
+    for use_ops in (False, True):
+        buf = make_buffer(spec, N, T, mb)
+        _fill_training_buffer(spec, buf, N, T)
+        m2 = make_model(spec, params)
+        ws = torch.empty(int(M.workspace_bytes(net_i, net_f, mb)), dtype=torch.uint8, device=DEV)
+        grads = torch.full((m2.param_count,), float('nan'), device=DEV)
+        metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
+        m1, mv, gn = torch.zeros_like(m2.flat), torch.zeros_like(m2.flat), torch.zeros(1, device=DEV)
+        scratch = torch.empty(4096, dtype=torch.uint8, device=DEV)
+        mean_f, std_f = torch.zeros(spec['obs'], device=DEV), torch.ones(spec['obs'], device=DEV)
+        if use_ops:
+            args, _ = rollout_args(buf)
+            M.ppo_grad(net_i, net_f, m2.flat, [0.2, 4.0, 0.01, 1e-4], [0, 0, 0], *args, mb, mb, mean_f, std_f, -5.0, 5.0, grads, metrics, ws)
+            M.clip_adam_step_(m2.flat, grads, m1, mv, 5e-4, 0.9, 0.999, 1e-5, 0.01, True, 1, 0.5, 1.0, gn, scratch)
+        else:
+            chp = hip.PpoHp(0.2, 4.0, 0.01, 1e-4, 0, 0, 0)
+            hip.check(L.mrl_ppo_grad(m2.net, hip.ptr(m2.flat), chp, buf.c, mb, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads),
+                                     hip.ptr(metrics), hip.ptr(ws), ws.numel(), None), 'grad')
+            hip.check(L.mrl_adam_step(hip.ptr(m2.flat), hip.ptr(grads), hip.ptr(m1), hip.ptr(mv), m2.param_count, 5e-4, 0.9, 0.999, 1e-5, 0.01, 1, 1, 0.5,
+                                      1.0, hip.ptr(gn), hip.ptr(scratch), None), 'adam')
+        torch.cuda.synchronize()
+        outs.append((grads.clone(), m2.flat.clone(), metrics.clone(), gn.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all()
+
+    # --- running statistics
+    r = RunningMeanStd((6,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    x = dev(synth.gaussianish((50, 6), 100) * 2 + 0.3)
+    want_n = None
+    bm, bv = x.mean(0), x.var(0, correction=1)
+    mean, var, cnt = r.running_mean.clone(), r.running_var.clone(), r.running_count.clone()
+    r.update(x)
+    M.welford_update_(mean, var, cnt, 1e-5, bm, bv, 50.0, None, None)
+    assert torch.allclose(mean, r.running_mean, rtol=1e-6, atol=1e-9) and cnt.item() == r.running_count.item()
+    y = M.normalize_clamp(x * 3, r.running_mean, r.running_var, r.running_count, 1e-5, -5.0, 5.0, False)
+    assert torch.equal(y, r.normalize(x * 3))
+    with pytest.raises(NotImplementedError):
+        M.normalize_clamp(x.cpu(), r.running_mean.cpu(), r.running_var.cpu(), r.running_count.cpu(), 1e-5, -5.0, 5.0, False)
+
+
+@pytest.mark.gpu
 def test_one_rank_rccl_group_matches_the_single_process_path():
     """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
     issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's

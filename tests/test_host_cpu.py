@@ -254,3 +254,20 @@ def test_host_classes_accept_the_dflex_ant_shapes():
     buf.storage_dict['obses']['obs'].copy_(torch.ones(4, 3, 37))
     assert float(buf.obs_store[:, :, 37:].abs().max()) == 0.0
     assert buf.prepare_training()['obses']['obs'].shape == (12, 37)
+
+
+def test_custom_operators_are_registered_for_the_device_only():
+    """mineral_amd/ops.py registers the C ABI's entry points under torch.ops.mineral for the CUDA (ROCm) dispatch key; the
+    host-only queries answer here, a call with CPU tensors is refused by the dispatcher (no CPU fallback)."""
+    import torch
+    import mineral_amd.ops as ops
+    for n in ops.OPS:
+        assert hasattr(torch.ops.mineral, n), n
+    net_i, net_f = [64, 12, 1, 0, 0, 512, 256, 128], [0.1, 1.0, 1e-5]
+    assert torch.ops.mineral.param_count(net_i, net_f) == 401820
+    assert torch.ops.mineral.workspace_bytes(net_i, net_f, 2048) > 0
+    with pytest.raises(ValueError):
+        torch.ops.mineral.param_count([63, 12, 1, 0, 0, 512], net_f)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mineral.clip_adam_step_(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 1, 0.0, 1.0,
+                                          None, torch.zeros(4096, dtype=torch.uint8))
