@@ -23,7 +23,7 @@ ktrace-ablate: $(SRC) $(HDR)
 	mkdir -p tools/bin && $(HIPCC) $(HIPFLAGS) -DMRL_KTRACE -DMRL_KTRACE_ABLATE $(SRC) -o tools/bin/libmineral_ppo_ktrace.so
 
 # stand-alone measurement programs (run on the GPU box: tools/bin travels with the tree)
-PROBES = mfma_peak_probe mfma_overlap_probe placement_probe bf16x3_split_probe
+PROBES = mfma_peak_probe mfma_overlap_probe placement_probe bf16x3_split_probe mfma_shape_probe
 probes:
 	mkdir -p tools/bin && for p in $(PROBES); do $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops tools/$$p.hip -o tools/bin/$$p || exit 1; done
 
