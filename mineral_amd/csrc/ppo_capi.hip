@@ -1213,6 +1213,7 @@ __global__ __launch_bounds__(192) void metrics_final_kernel(const double* __rest
   __shared__ double s[MRL_NMETRIC];
   const int m = threadIdx.x % MRL_NMETRIC, j = threadIdx.x / MRL_NMETRIC;
   double a = 0;
+#pragma unroll 8   // the loads of eight blocks in flight at once; the adds keep their order
   for (int b = j; b < nblocks; b += 16)
     a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + m] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + m];
   red[j][m] = a;
@@ -1618,8 +1619,43 @@ static bool bwd_uses_planes(const mrl_net* net, const ParamLayout& L, int64_t mb
 // planes_ready: the caller has already refreshed the weight planes of the workspace on a stream this one is ordered behind
 static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
-                              float* const* input_grad, hipStream_t s, bool planes_ready = false) {
+                              float* const* input_grad, hipStream_t s, bool planes_ready = false, hipStream_t wgrad_stream = nullptr,
+                              hipEvent_t* wgrad_events = nullptr) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  // weight-gradient slabs of layer l (l == last + 1: the heads) on stream st
+  auto wgrad_of = [&](int l, hipStream_t st) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    const bool head = (l == last + 1);
+    const int gm = head ? 32 : net->units[l];
+    const int gn = head ? U : L.in_dim[l];
+    const WgradPlan& wp = head ? W.wph : W.wp[l];
+    for (int k = 0; k < towers; ++k) {
+      const int tw = tw0 + k;
+      p.A[k] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
+      p.B[k] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
+      p.pro0[k] = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
+      p.pro1[k] = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
+      p.out[k] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
+      p.Nt[k] = gn; p.Kt[k] = (int)mb;
+    }
+    p.lda = gm; p.ldb = gn; p.ldo = gn;
+    p.M = gm; p.N = gn; p.K = (int)mb;
+    p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
+    p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
+    p.n_groups = wp.nsplit; p.group_mode = 1;
+    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : (L.has_norm ? (net->tower_kind == TOWER_LAYERNORM_ELU ? PRO_LNELU : PRO_LNSILU) : PRO_ELU), towers, st);
+  };
+  // With a weight-gradient stream, the slabs of layer l are launched there as soon as dZ of layer l is final on s, beside
+  // the rest of the dgrad chain (they only read dZ[l] and xhat[l-1]; every layer has buffers of its own).  The caller joins
+  // that stream before it reduces the slabs.
+  const bool side_wgrad = wgrad && wgrad_stream && wgrad_events;
+  auto wgrad_beside = [&](int l) {
+    hipEvent_t e = wgrad_events[l];
+    if (hipEventRecord(e, s) == hipSuccess && hipStreamWaitEvent(wgrad_stream, e, 0) == hipSuccess) wgrad_of(l, wgrad_stream);
+    else wgrad_of(l, s);   // ordering on s is always sufficient
+  };
+  if (side_wgrad) wgrad_beside(last + 1);
   const unsigned short* planes = nullptr;             // refreshed here: the caller may have changed the parameters since the forward
   if (bwd_uses_planes(net, L, mb))
     planes = planes_ready ? reinterpret_cast<const unsigned short*>(ws + W.wplanes) : launch_split_params(L, W, ws, params, s);
@@ -1694,6 +1730,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
       else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
     }
+    if (side_wgrad) wgrad_beside(l);
   }
 
   // ---- gradient with respect to the input of the first layer: dX = dZ0 * W0 ----------------------------------------
@@ -1714,32 +1751,8 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.n_groups = p.m_tiles; p.group_mode = 0;
     launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
   }
-  if (!wgrad) return;
-
-  // ---- wgrad partial slabs -----------------------------------------------------------------------------------------
-  for (int l = last + 1; l >= 0; --l) {
-    GemmP p;
-    memset(&p, 0, sizeof(p));
-    const bool head = (l == last + 1);
-    const int gm = head ? 32 : net->units[l];
-    const int gn = head ? U : L.in_dim[l];
-    const WgradPlan& wp = head ? W.wph : W.wp[l];
-    for (int k = 0; k < towers; ++k) {
-      const int tw = tw0 + k;
-      p.A[k] = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
-      p.B[k] = (l == 0) ? x : ws + W.xhat[tw][l - 1];
-      p.pro0[k] = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
-      p.pro1[k] = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
-      p.out[k] = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
-      p.Nt[k] = gn; p.Kt[k] = (int)mb;
-    }
-    p.lda = gm; p.ldb = gn; p.ldo = gn;
-    p.M = gm; p.N = gn; p.K = (int)mb;
-    p.clamp_lo = clamp_lo; p.clamp_hi = clamp_hi;
-    p.ksplit = wp.ksplit; p.m_tiles = wp.tiles_m; p.n_tiles = wp.tiles_n;
-    p.n_groups = wp.nsplit; p.group_mode = 1;
-    launch_wgrad(p, wp, (l == 0) ? (obs_mean ? PRO_NORM : PRO_NONE) : (L.has_norm ? (net->tower_kind == TOWER_LAYERNORM_ELU ? PRO_LNELU : PRO_LNSILU) : PRO_ELU), towers, s);
-  }
+  if (!wgrad || side_wgrad) return;
+  for (int l = last + 1; l >= 0; --l) wgrad_of(l, s);
 }
 
 // Fixed-order reduction of the partial slabs, column partials and head-bias partials of towers tw0 .. tw0+towers-1
@@ -1782,7 +1795,11 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
 
 // A second stream per device for the per-tower launch chains of mrl_ppo_grad (actor on the caller's stream, critic on this
 // one; both at the default priority), with the two events of the fork and the join.  Created on first use, never destroyed.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream {
+  hipStream_t s = nullptr, w[2] = {nullptr, nullptr};   // critic chain; weight-gradient launches of each tower chain
+  hipEvent_t fork = nullptr, join = nullptr, wjoin[2] = {nullptr, nullptr};
+  hipEvent_t wev[2][MRL_MAX_LAYERS + 2] = {};
+};
 static SideStream g_side[MRL_MAX_DEVICES];
 static int side_stream(SideStream** out) {
   int dev = -1;
@@ -1797,6 +1814,12 @@ static int side_stream(SideStream** out) {
       if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) MRL_FAIL(MRL_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
       if ((e = hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ss.join, hipEventDisableTiming)) != hipSuccess)
         MRL_FAIL(MRL_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+      for (int k = 0; k < 2; ++k) {
+        if ((e = hipStreamCreateWithFlags(&ss.w[k], hipStreamNonBlocking)) != hipSuccess) MRL_FAIL(MRL_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        if ((e = hipEventCreateWithFlags(&ss.wjoin[k], hipEventDisableTiming)) != hipSuccess) MRL_FAIL(MRL_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+        for (int l = 0; l < MRL_MAX_LAYERS + 2; ++l)
+          if ((e = hipEventCreateWithFlags(&ss.wev[k][l], hipEventDisableTiming)) != hipSuccess) MRL_FAIL(MRL_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+      }
       ss.s = st;
     }
   }
@@ -1805,7 +1828,9 @@ static int side_stream(SideStream** out) {
 }
 // Launch structure of mrl_ppo_grad.  false: both towers in every launch (blockIdx.z).  true: one launch chain per tower on
 // two streams, so that the store bursts and epilogues of one tower's kernels run beside the main loops of the other's
-// (bit-identical results; measured 248.7 -> 243.0 ms per full-size update).  Default: two streams for batches above
+// (bit-identical results; measured 248.7 -> 243.0 ms per full-size update), and the weight-gradient launches of each
+// chain on a third and fourth stream beside the rest of its dgrad chain (another 1.3 %: 249.6 / 248.3 -> 246.0 / 245.4 ms
+// in two A/B pairs on one box).  Default: two streams for batches above
 // MRL_SMALL_M rows, where every launch fills the chip several times over; MRL_TOWER_STREAMS=0 / 1 in the environment forces
 // one or the other.  While kernel timing is on (mrl_profile_enable) the single-stream order is used.
 static bool tower_streams(int64_t mb) {
@@ -1885,7 +1910,11 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
       hipStream_t st = tw == 0 ? s : ss->s;
       launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, st, wpl);
       launch_heads(tw, 1, st);
-      launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, true, nullptr, st, planes);
+      // weight-gradient launches of each chain on a stream of their own (MRL_WGRAD_STREAMS=0 keeps them in the chain)
+      static const int wside = [] { const char* e = getenv("MRL_WGRAD_STREAMS"); return e ? atoi(e) : 1; }();
+      launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, true, nullptr, st, planes, wside ? ss->w[tw] : nullptr, ss->wev[tw]);
+      if (wside && (hipEventRecord(ss->wjoin[tw], ss->w[tw]) != hipSuccess || hipStreamWaitEvent(st, ss->wjoin[tw], 0) != hipSuccess))
+        MRL_FAIL(MRL_EHIP, "join of the weight-gradient stream failed");
       launch_grad_reduce(net, L, W, ws, grads, tw, 1, hblocks, st);
     }
     if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "join of the tower streams failed");

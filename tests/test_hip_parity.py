@@ -840,8 +840,9 @@ def test_one_rank_rccl_group_matches_the_single_process_path():
 
 @pytest.mark.gpu
 def test_per_tower_stream_chains_are_bit_identical_to_the_single_stream_launches():
-    """Above 8192 rows mrl_ppo_grad runs the actor and the critic chain on two streams (fork / join by events).  Same kernels,
-    same fixed-order reductions: the parameters after two updates must equal those of the one-stream launch order bit for bit."""
+    """Above 8192 rows mrl_ppo_grad runs the actor and the critic chain on two streams and the weight-gradient launches of each
+    chain on a further stream (fork / join by events).  Same kernels, same fixed-order reductions: the parameters after two
+    updates must equal those of the one-stream launch order bit for bit."""
     import json
     import subprocess
     import sys
