@@ -92,7 +92,7 @@ def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` at this workload, from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs by tools/pmc_traffic.sh and cannot be read from inside this process);
     None when no measurement of that kernel is on file."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
     try:
         with open(path) as f:
             return json.load(f)['kernels'][kernel]['hbm_bytes']

@@ -43,6 +43,7 @@ extern "C" {
 
 #define MRL_TOWER_LAYERNORM_SILU 0   /* [Linear -> LayerNorm -> SiLU] per layer (DFlexAntPPO.yaml, AllegroHandPPO.yaml) */
 #define MRL_TOWER_ELU 1              /* [Linear -> ELU] per layer, no normalisation (CartpolePPO.yaml) */
+#define MRL_TOWER_LAYERNORM_ELU 2     /* [Linear -> LayerNorm -> ELU] per layer (the mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) */
 
 /* ActorCritic description: two towers of n_layers hidden layers, heads mu/sigma (actor) and value (critic).
  * mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.

@@ -193,7 +193,7 @@ def require_current_device(device):
     return index
 
 
-TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1}   # (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
+TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1, ('LayerNorm', 'ELU'): 2}   # (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
 
 
 def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=1e-5, tower_kind=0, fixed_sigma=False):

@@ -66,7 +66,7 @@ static int check_net(const mrl_net* net) {
     if (!(u == 32 || u == 64 || u == 128 || u == 256 || u == 512)) MRL_FAIL(MRL_EINVAL, "units[%d]=%d must be 32/64/128/256/512", l, u);
   }
   if (net->dist_type != MRL_DIST_NORMAL && net->dist_type != MRL_DIST_DREAMERV3_NORMAL) MRL_FAIL(MRL_EINVAL, "dist_type %d unsupported", net->dist_type);
-  if (net->tower_kind != MRL_TOWER_LAYERNORM_SILU && net->tower_kind != MRL_TOWER_ELU) MRL_FAIL(MRL_EINVAL, "tower_kind %d unsupported", net->tower_kind);
+  if (net->tower_kind != MRL_TOWER_LAYERNORM_SILU && net->tower_kind != MRL_TOWER_ELU && net->tower_kind != MRL_TOWER_LAYERNORM_ELU) MRL_FAIL(MRL_EINVAL, "tower_kind %d unsupported", net->tower_kind);
   if (net->fixed_sigma != 0 && net->fixed_sigma != 1) MRL_FAIL(MRL_EINVAL, "fixed_sigma %d not in {0, 1}", net->fixed_sigma);
   return MRL_OK;
 }
@@ -103,7 +103,7 @@ static void param_layout_ex(int in_dim0, int n_layers, const int32_t* units, int
   L->total = o;
 }
 
-constexpr int TOWER_LAYERNORM_ELU = 2;   // LayerNorm + ELU: the critic of DFlexAntSHAC.yaml; reached through the critic entry points only
+constexpr int TOWER_LAYERNORM_ELU = MRL_TOWER_LAYERNORM_ELU;   // LayerNorm + ELU (also the critic of DFlexAntSHAC.yaml)
 
 // ActorCritic: actor tower with the [mu; sigma] head (or the mu head with [mu bias; log-std] when sigma is fixed), critic
 // tower with the value head
@@ -1377,6 +1377,7 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     p.clamp_lo = value_rms->clamp_lo; p.clamp_hi = value_rms->clamp_hi;
   }
   if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   MRL_CHECK_LAUNCH("mrl_policy_act");
   return MRL_OK;
@@ -1499,6 +1500,7 @@ extern "C" int mrl_policy_mean(const mrl_net* net, const float* params, const mr
   p.h.mu = mu_out;
   p.h.out_rs = A; p.h.out_off = 0;
   if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
+  else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
   else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
   MRL_CHECK_LAUNCH("mrl_policy_mean");
   return MRL_OK;
@@ -1897,6 +1899,7 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
     p.h.smooth_clamp = hp->use_smooth_clamp != 0;
     if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, towers), st);
+    else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNELU>(p, dim3(hblocks, 1, towers), st);
     else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, towers), st);
   };
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels

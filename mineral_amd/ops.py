@@ -9,7 +9,7 @@ calling an operator with CPU tensors fails in the dispatcher instead of falling 
     torch.ops.mineral.gae_finish(rewards_tn, values_tn, dones_tn, neglogp_tn, last_values, 0.99, 0.95, ...)
 
 Network description for the operators that run the towers: `net_i` = [obs_dim, act_dim, dist_type, tower_kind, fixed_sigma,
-units...] (dist_type 0 normal / 1 dreamerv3_normal; tower_kind 0 LayerNorm+SiLU / 1 ELU) and `net_f` = [minstd, maxstd, ln_eps].
+units...] (dist_type 0 normal / 1 dreamerv3_normal; tower_kind 0 LayerNorm+SiLU / 1 ELU / 2 LayerNorm+ELU) and `net_f` = [minstd, maxstd, ln_eps].
 """
 
 import torch

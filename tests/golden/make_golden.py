@@ -158,6 +158,10 @@ NETS = {
     # device kernels take
     'cartpole': dict(obs=4, act=1, units=[32, 32], norm=None, act_type='ELU', fixed_sigma=True, dist=dict(dist_type='normal')),
 }
+# LayerNorm + ELU towers (the mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) in the PPO ActorCritic; kept out of NETS so
+# that g4() keeps writing exactly the files it wrote before
+LNELU = dict(obs=64, act=12, units=[128, 64, 32], norm='LayerNorm', act_type='ELU', fixed_sigma=False,
+             dist=dict(dist_type='dreamerv3_normal', minstd=0.1, maxstd=1.0))
 
 
 def build_model(spec, seed):
@@ -173,8 +177,8 @@ def build_model(spec, seed):
     return m
 
 
-def g4():
-    for tag, spec in NETS.items():
+def g4(nets=None):
+    for tag, spec in (nets or NETS).items():
         m = build_model(spec, 3)
         B = 16
         obs = synth.gaussianish((B, spec['obs']), 41)
@@ -352,6 +356,13 @@ def g8_full():
               params_every_epoch=False)
 
 
+def g_lnelu():
+    """LayerNorm + ELU towers: the module's outputs and one recorded PPO.train()."""
+    g4({'mid_lnelu': LNELU})
+    run_agent('g8_train_mid_lnelu_adamw', LNELU, N=64, T=8, mb=128, mini_epochs=2, epochs=2, optim_type='AdamW',
+              params_every_epoch=False)
+
+
 def g16_checkpoint():
     """A checkpoint written by the REFERENCE's PPO.save after one epoch, and the reference's own continuation from it (a fresh
     agent and env, PPO.load, one more epoch).  The product has to load the same file and continue the same way."""
@@ -387,7 +398,7 @@ if __name__ == '__main__':
     only = os.environ.get('GOLDEN_ONLY')                    # add fixtures without rewriting the others
     if only:
         for name in only.split(','):
-            {'g4': g4, 'g8_cartpole': g8_cartpole, 'g8_full': g8_full, 'g16_checkpoint': g16_checkpoint}[name]()
+            {'g4': g4, 'g8_cartpole': g8_cartpole, 'g8_full': g8_full, 'g16_checkpoint': g16_checkpoint, 'lnelu': g_lnelu}[name]()
         sys.exit(0)
     g1_g2()
     g3()
@@ -397,4 +408,5 @@ if __name__ == '__main__':
     g8_cartpole()
     g8_full()
     g16_checkpoint()
+    g_lnelu()
     g9_g10()

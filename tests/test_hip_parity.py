@@ -63,6 +63,9 @@ NETS = {
     'ln_fixed': dict(obs=64, act=12, units=[128, 64], fixed=True),
     'obs128': dict(obs=128, act=12, units=[128, 128]),
     'odd_heads': dict(obs=64, act=3, units=[256, 128]),     # 6-row heads: the tensors behind them start on odd offsets
+    # LayerNorm + ELU towers (mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) in the PPO ActorCritic
+    'mid_lnelu': dict(obs=64, act=12, units=[128, 64, 32], actf='ELU'),
+    'full_lnelu': dict(obs=64, act=12, units=[512, 256, 128], actf='ELU'),
 }
 
 
@@ -170,7 +173,8 @@ def test_batch_moments_groups(hip):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('net,N,dist', [('mid', 64, 'dreamerv3_normal'), ('full', 16, 'dreamerv3_normal'), ('full', 300, 'normal'),
                                        ('wide2', 129, 'dreamerv3_normal'), ('cartpole', 100, 'normal'), ('elu_wide', 300, 'normal'),
-                                       ('elu_head', 77, 'dreamerv3_normal'), ('ln_fixed', 64, 'normal')])
+                                       ('elu_head', 77, 'dreamerv3_normal'), ('ln_fixed', 64, 'normal'),
+                                       ('mid_lnelu', 16, 'dreamerv3_normal'), ('full_lnelu', 300, 'normal')])
 def test_policy_act(hip, golden, net, N, dist):
     from mineral_amd.common.normalizers import RunningMeanStd
     spec = NETS[net]
@@ -212,9 +216,9 @@ def test_policy_act(hip, golden, net, N, dist):
     hip.check(L.mrl_policy_act(model.net, hip.ptr(model.flat), obs_rms.c_struct(), value_rms.c_struct(), hip.ptr(d_obs),
                                None, T, buf.c, None, hip.ptr(last), hip.ptr(ws), ws.numel(), None), 'act boot')
     assert_close(cpu(last), ref_v.squeeze(1), **tol, what='last_values')
-    if net == 'full' and N == 16 and dist == 'dreamerv3_normal':
+    if (net == 'full' or net == 'mid_lnelu') and N == 16 and dist == 'dreamerv3_normal':
         # the reference's own outputs for this network (no normalisers): golden g4
-        g = golden('g4_model_full_dv3')
+        g = golden('g4_model_full_dv3' if net == 'full' else 'g4_model_mid_lnelu')
         ident_o = RunningMeanStd((spec['obs'],), eps=0.0, with_clamp=True, initial_count=1, device=DEV)
         buf4 = make_buffer(spec, 16, 1)
         hip.check(L.mrl_policy_act(model.net, hip.ptr(model.flat), None, None, hip.ptr(d_obs), hip.ptr(d_noise), 0, buf4.c,
@@ -265,6 +269,9 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('elu_wide', 50, 8, 200, 'normal', 0, 'bound'),
     ('elu_head', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
     ('ln_fixed', 64, 8, 256, 'normal', 0, 'bound'),
+    ('mid_lnelu', 64, 8, 128, 'dreamerv3_normal', 0, 'bound'),
+    ('full_lnelu', 64, 8, 256, 'normal', 1, 'reg'),
+    ('full_lnelu', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),     # split-bf16 kernels with the ELU prologue / derivative
     # minibatches of 8192 rows and more take the weight gradients of whole-128 layers through the split-bf16 kernel; 8328 rows
     # end in a partial 16-row step
     ('full', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
@@ -418,11 +425,12 @@ def _agent_cfg(spec, N, T, mb, mini_epochs, epochs, optim, logdir):
 
 
 @pytest.mark.parametrize('fixture,net,optim,mb', [('g8_train_mid_dv3_adamw', 'mid', 'AdamW', 128), ('g8_train_cartpole_adam', 'cartpole', 'Adam', 128),
-                                                  ('g8_train_full_dv3_adamw', 'full', 'AdamW', 256)])
+                                                  ('g8_train_full_dv3_adamw', 'full', 'AdamW', 256),
+                                                  ('g8_train_mid_lnelu_adamw', 'mid_lnelu', 'AdamW', 128)])
 def test_end_to_end_training_vs_reference_golden(hip, golden, tmp_path, fixture, net, optim, mb):
     """PPO.train() of the product on the deterministic env against what the REFERENCE produced: the LayerNorm+SiLU net
-    with a sigma head (fixture g8 mid), the network of CartpolePPO.yaml (no norm, ELU, state-independent log-std) and the
-    DFlexAntPPO network itself ([512, 256, 128])."""
+    with a sigma head (fixture g8 mid), the network of CartpolePPO.yaml (no norm, ELU, state-independent log-std), the
+    DFlexAntPPO network itself ([512, 256, 128]) and LayerNorm + ELU towers."""
     from mineral_amd.agents import PPO
     g = golden(fixture)
     spec = NETS[net]

@@ -92,8 +92,10 @@ def test_parameter_views_match_reference_names_and_count():
     assert [n for n, _ in c.named_parameters()] == [n for n, _ in cshapes]
     assert all(tuple(v.shape) == s for (_, v), (_, s) in zip(c.named_parameters(), cshapes))
     assert float(c.state_dict()['sigma'].abs().sum()) == 0            # models.py:87-88
+    e = ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='ELU'), fixed_sigma=True, device='cpu')
+    assert e.net.tower_kind == 2 and 'mu.weight' in e.state_dict()    # LayerNorm + ELU towers: same layout as LayerNorm + SiLU
     with pytest.raises(NotImplementedError):                           # pairs without kernels
-        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='ELU'), fixed_sigma=True, device='cpu')
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='Tanh'), fixed_sigma=True, device='cpu')
     with pytest.raises(NotImplementedError):
         ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ReLU'), fixed_sigma=False, device='cpu')
 
