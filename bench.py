@@ -184,8 +184,8 @@ def main():
     dominant, dt_events = None, None
     if timing:
         # the same K steps once more with HIP events around every launch of the dominant kernel, on the stream it is launched
-        # on.  With events on, the library issues one launch per kernel (both towers) on one stream, so a launch's duration is
-        # its own; the timed region above overlaps the two towers' launch chains on two streams.
+        # on.  With events on, the library issues every launch in order, so a launch's duration is its own; in the timed region
+        # above the weight-gradient launches run beside the dgrad launches (any-order launches).
         L.mrl_profile_enable(2 if args.warmup > 0 else 1)
         fence()
         t1 = time.perf_counter()
@@ -269,7 +269,7 @@ def main():
                                    'peak_basis': ('dense bf16 MFMA peak 2500 / 6 split terms per fp32 product' if split else 'dense fp32 MFMA peak'),
                                    'frac_of_fp32_mfma_peak': achieved / 157.3,
                                    'measured_over': f'a second pass of the same {args.steps} steps with HIP events around every launch of this kernel '
-                                                    f'(single-stream launch order), {1e3 * dt_events / args.steps:.1f} ms per step'}
+                                                    f'(every launch in order), {1e3 * dt_events / args.steps:.1f} ms per step'}
                 if kernel_table:
                     out['roofline']['kernels'] = kernel_table
         if not args.no_secondary and not multi and args.minibatch != 2048:

@@ -4,6 +4,7 @@
 #include "gemm.hip.h"
 #include "split_bf16.hip.h"
 
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -346,6 +347,23 @@ extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
 }
 #endif
 
+// A launch that does not wait for the launches before it on its stream (hipExtAnyOrderLaunch: the dispatch packet goes out
+// without the barrier bit): set around a launch whose inputs are complete once the launch before it has STARTED, so that
+// the two run side by side; the next ordinary launch waits for both.  Used for the weight-gradient launches of the backward
+// chain (each goes out right behind the dgrad launch that reads the same dZ) and the metrics reduction behind the slab
+// reduction: the same 2 % per update as separate streams with events (234.7 against 238.8 ms, streams 234.9) without
+// either.  MRL_ANY_ORDER=0 in the environment switches it off; it is off while kernels are being timed.
+static thread_local bool g_any_order = false;
+static bool any_order_enabled() {
+  static const int on = [] { const char* e = getenv("MRL_ANY_ORDER"); return e ? atoi(e) : 1; }();
+  return on != 0 && g_prof_mode == 0;
+}
+#define MRL_LAUNCH(kernel, grid, block, lds, stream, arg)                                                                  \
+  do {                                                                                                                    \
+    if (g_any_order) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, nullptr, hipExtAnyOrderLaunch, arg); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, arg);                                                       \
+  } while (0)
+
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI, int PRO, int NBUF = 2, int MM = 0>
 static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident = 0) {
   using Cfg = GemmCfg<BM, BN, BK, WGM, WGN, LA, LB, EPI>;
@@ -382,7 +400,7 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
   }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM>), grid, dim3(64 * WGM * WGN), dyn_lds, s, pt);
 #else
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM>), grid, dim3(64 * WGM * WGN), dyn_lds, s, p);
+  MRL_LAUNCH((gemm_kernel<BM, BN, BK, WGM, WGN, LA, LB, EPI, PRO, NBUF, MM>), grid, dim3(64 * WGM * WGN), dyn_lds, s, p);
 #endif
   if (timed) {
     (void)hipEventRecord(e1, s);
@@ -450,7 +468,7 @@ static void launch_wgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  hipLaunchKernelGGL((wgrad_split_kernel<PRO, BNT, BMT>), grid, dim3(BMT * 2), 0, s, p);
+  MRL_LAUNCH((wgrad_split_kernel<PRO, BNT, BMT>), grid, dim3(BMT * 2), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
     ProfClass& c = g_prof[cls];
@@ -1651,11 +1669,21 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
   // With a weight-gradient stream, the slabs of layer l are launched there as soon as dZ of layer l is final on s, beside
   // the rest of the dgrad chain (they only read dZ[l] and xhat[l-1]; every layer has buffers of its own).  The caller joins
   // that stream before it reduces the slabs.
-  const bool side_wgrad = wgrad && wgrad_stream && wgrad_events;
+  const bool pair_wgrad = wgrad && !(wgrad_stream && wgrad_events) && any_order_enabled();
+  const bool side_wgrad = wgrad && ((wgrad_stream && wgrad_events) || pair_wgrad);
+  int pending = -1;   // pair_wgrad: the layer whose weight gradient goes out right behind the next dgrad launch, beside it
   auto wgrad_beside = [&](int l) {
+    if (pair_wgrad) { pending = l; return; }
     hipEvent_t e = wgrad_events[l];
     if (hipEventRecord(e, s) == hipSuccess && hipStreamWaitEvent(wgrad_stream, e, 0) == hipSuccess) wgrad_of(l, wgrad_stream);
     else wgrad_of(l, s);   // ordering on s is always sufficient
+  };
+  auto flush_pending = [&](bool beside) {
+    if (pending < 0) return;
+    g_any_order = beside;
+    wgrad_of(pending, s);
+    g_any_order = false;
+    pending = -1;
   };
   if (side_wgrad) wgrad_beside(last + 1);
   const unsigned short* planes = nullptr;             // refreshed here: the caller may have changed the parameters since the forward
@@ -1699,6 +1727,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
       else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
       else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_ACTBWD, PRO_NONE>(p, grid, s);
+      flush_pending(true);
     } else if (ln_bwd_streamed(u)) {
       // plain dgrad tile grid (no full-row constraint), then the streaming LayerNorm/SiLU backward in place
       p.ksplit = kdim; p.n_tiles = u / 128; p.group_mode = 0;
@@ -1711,6 +1740,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
         if (l != last && kdim % 16 == 0) launch_dgrad_split(p, grid, s);   // A = dZ of the layer above, all K columns valid
         else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, grid, s);
       }
+      flush_pending(true);
       LnBwdArgs a;
       memset(&a, 0, sizeof(a));
       for (int k = 0; k < towers; ++k) {
@@ -1731,6 +1761,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       else if (u == 128) launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
       else if (u == 64) launch_gemm<128, 64, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
       else launch_gemm<128, 32, 16, 4, 1, LAY_K, LAY_R, EPI_LNBWD, PRO_NONE>(p, grid, s);
+      flush_pending(true);
     }
     if (side_wgrad) wgrad_beside(l);
   }
@@ -1752,7 +1783,9 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     p.ksplit = u0; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = (int)cdiv(in0, 128);
     p.n_groups = p.m_tiles; p.group_mode = 0;
     launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+    flush_pending(true);
   }
+  flush_pending(false);   // the first layer's weight gradient when no launch is left to run beside
   if (!wgrad || side_wgrad) return;
   for (int l = last + 1; l >= 0; --l) wgrad_of(l, s);
 }
@@ -1828,17 +1861,17 @@ static int side_stream(SideStream** out) {
   *out = &ss;
   return MRL_OK;
 }
-// Launch structure of mrl_ppo_grad.  false: both towers in every launch (blockIdx.z).  true: one launch chain per tower on
+// Alternative launch structure of mrl_ppo_grad, kept as a measured variant (MRL_TOWER_STREAMS=1; same results, same speed as
+// the default of one stream with any-order weight-gradient launches).  false: both towers in every launch (blockIdx.z).  true: one launch chain per tower on
 // two streams, so that the store bursts and epilogues of one tower's kernels run beside the main loops of the other's
 // (bit-identical results; measured 248.7 -> 243.0 ms per full-size update), and the weight-gradient launches of each
 // chain on a third and fourth stream beside the rest of its dgrad chain (another 1.3 %: 249.6 / 248.3 -> 246.0 / 245.4 ms
-// in two A/B pairs on one box).  Default: two streams for batches above
-// MRL_SMALL_M rows, where every launch fills the chip several times over; MRL_TOWER_STREAMS=0 / 1 in the environment forces
-// one or the other.  While kernel timing is on (mrl_profile_enable) the single-stream order is used.
+// in two A/B pairs on one box).  Only for batches above MRL_SMALL_M rows, where every launch fills the chip several times
+// over.  While kernel timing is on (mrl_profile_enable) the single-stream order is used.
 static bool tower_streams(int64_t mb) {
   static const int forced = [] { const char* e = getenv("MRL_TOWER_STREAMS"); return e ? atoi(e) : -1; }();
   if (g_prof_mode != 0) return false;   // per-kernel timing wants one launch per kernel and nothing running beside it
-  return forced >= 0 ? forced != 0 : mb > MRL_SMALL_M;
+  return forced > 0 && mb > MRL_SMALL_M;
 }
 
 extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
@@ -1927,8 +1960,14 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes);
     launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   }
-  hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
-                     hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+  {
+    if (any_order_enabled())   // beside the slab reduction launched just before it: it reads what the heads launch left long ago
+      hipExtLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, metric_part, hblocks, (double)mb,
+                            hp->critic_coef, hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+    else
+      hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
+                         hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+  }
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
   return MRL_OK;
 }

@@ -847,22 +847,23 @@ def test_one_rank_rccl_group_matches_the_single_process_path():
 
 
 @pytest.mark.gpu
-def test_per_tower_stream_chains_are_bit_identical_to_the_single_stream_launches():
-    """Above 8192 rows mrl_ppo_grad runs the actor and the critic chain on two streams and the weight-gradient launches of each
-    chain on a further stream (fork / join by events).  Same kernels, same fixed-order reductions: the parameters after two
-    updates must equal those of the one-stream launch order bit for bit."""
+def test_launch_structures_of_the_update_are_bit_identical():
+    """Above 8192 rows mrl_ppo_grad lets the weight-gradient launches run beside the dgrad launch that reads the same dZ
+    (any-order launches on the caller's stream; MRL_ANY_ORDER=0 keeps every launch in order), or, with MRL_TOWER_STREAMS=1,
+    runs one launch chain per tower plus the weight gradients on library-owned streams (fork / join by events).  Same
+    kernels, same fixed-order reductions: the parameters after two updates must be equal bit for bit in all three."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
-    for mode in ('0', '1'):
+    for env in (dict(MRL_ANY_ORDER='0', MRL_TOWER_STREAMS='0'), dict(MRL_ANY_ORDER='1', MRL_TOWER_STREAMS='0'), dict(MRL_TOWER_STREAMS='1')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '16384',
                '--no-kernel-timing', '--no-cpu-baseline']
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, MRL_TOWER_STREAMS=mode))
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, **env))
         assert res.returncode == 0, res.stderr[-2000:]
         sums.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])['param_checksum'])
-    assert sums[0] == sums[1]
+    assert sums[0] == sums[1] == sums[2]
 
 
 @pytest.mark.gpu
