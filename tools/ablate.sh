@@ -1,13 +1,13 @@
 #!/bin/bash
 # Diagnostic: builds of the library with parts of one split-bf16 kernel switched off (results are garbage; timing only) and
-# the per-kernel table of one full-size update for each.  Build on the CPU: tools/ablate.sh build "DGRAD=1 FWD=1 WGRAD=2 ..."
-# Run on the GPU box: tools/ablate.sh run "DGRAD=1 FWD=1 ..."
+# the per-kernel table of one full-size update for each.  Build on the CPU: tools/ablate.sh build "MRL_ABLATE_DGRAD=1 MRL_ABLATE_FWD=1 MRL_ABLATE_WGRAD=2 ..." (any -D macro)
+# Run on the GPU box: tools/ablate.sh run "MRL_ABLATE_DGRAD=1 ..."
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-value"
 if [ "$1" = build ]; then
   mkdir -p $R/tools/bin
   for v in $2; do
-    /opt/rocm/bin/hipcc $FLAGS -DMRL_ABLATE_$v $R/mineral_amd/csrc/ppo_capi.hip $R/mineral_amd/csrc/replay.hip -o $R/tools/bin/libmrl_abl_$v.so 2>/dev/null &
+    /opt/rocm/bin/hipcc $FLAGS -D$v $R/mineral_amd/csrc/ppo_capi.hip $R/mineral_amd/csrc/replay.hip -o $R/tools/bin/libmrl_abl_$v.so 2>/dev/null &
   done
   wait; ls $R/tools/bin/*.so
 else
