@@ -911,6 +911,29 @@ def test_launcher_cli_runs_the_cartpole_network(tmp_path):
 
 
 @pytest.mark.gpu
+def test_launcher_cli_runs_the_dflex_ant_config_at_four_envs(tmp_path):
+    """The reference's smallest case -- `agent=DFlexAntPPO` with num_envs=4 -- on DFlex Ant's shapes (37 observations, 8 actions)
+    through the launcher.  The simulator is not in the image, so the synthetic env supplies tensors of those shapes; the
+    reference runs this case on the CPU, the product on the device (it has no CPU path).  minibatch_size is the whole
+    4 x 32 batch, as the reference's own assert (ppo.py:83) demands of any override with so few envs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    logdir = str(tmp_path / 'run')
+    cmd = [sys.executable, '-m', 'mineral.scripts.run', 'task=Synthetic', 'agent=DFlexAntPPO', 'num_envs=4', 'task.env.obs_dim=37',
+           'task.env.act_dim=8', 'agent.ppo.minibatch_size=128', 'agent.ppo.max_agent_steps=512', 'agent.print_every=1', f'logdir={logdir}', 'seed=7']
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert 'Traceback' not in res.stderr and 'Exception:' not in res.stdout, (res.stdout[-1500:], res.stderr[-1500:])
+    ckpt = torch.load(os.path.join(logdir, 'ckpt', 'final.pth'), map_location='cpu', weights_only=True)
+    assert ckpt['agent_steps'] == 512 and ckpt['epoch'] == 3      # four updates; the counter starts at -1 (agent.py:79)
+    assert ckpt['model']['actor_mlp.mlp.0.weight'].shape == (512, 37) and ckpt['model']['mu.weight'].shape == (8, 128)
+    assert ckpt['obs_rms']['obs.running_mean'].shape == (37,)
+    assert all(torch.isfinite(v).all() for v in ckpt['model'].values())
+
+
+@pytest.mark.gpu
 def test_env_autoresets_false_resets_finished_envs_before_the_next_step(hip, tmp_path):
     """task.env_autoresets=False (ppo.py:136-142): finished envs are reset through env.reset_idx and their fresh observation is
     what the next policy step sees and stores."""
