@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
 // not stored.
 // WPL: the weights come from planes split beforehand (GemmP::Bpl) and go to LDS as they are.
 #ifndef MRL_ABLATE_DGRAD
-#define MRL_ABLATE_DGRAD 0   // diagnostic builds only (tools/ablate_dgrad.sh): bit 0 no output stores, 1 no split of A, 2 no MFMAs, 3 one step
+#define MRL_ABLATE_DGRAD 0   // diagnostic builds only (tools/ablate_dgrad.sh): bit 0 no output stores, 1 no split of A, 2 no MFMAs, 3 one step, 4 all blocks store to the same 128 rows
 #endif
 template <bool WPL>
 __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if ((ABL & 1) ? (row < p.M && acc[i][jn][r] == 1.2345e-30f) : (row < p.M)) out[(int64_t)row * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
+        const int srow = (ABL & 16) ? (row & 127) : row;   // timing-only: every block stores to the same 128 rows (cache-resident)
+        if ((ABL & 1) ? (row < p.M && acc[i][jn][r] == 1.2345e-30f) : (row < p.M)) out[(int64_t)srow * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
       }
 }
 
