@@ -847,6 +847,69 @@ def test_one_rank_rccl_group_matches_the_single_process_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mb', [256, 16384])
+def test_an_optimizer_step_replays_from_a_hip_graph(hip, mb):
+    """Callers may capture mrl_rms_merge -> mrl_ppo_grad -> mrl_adam_step into a HIP graph (the library allocates nothing and
+    records no memset; above 8192 rows it issues any-order launches).  Every replay, with eager work and synchronisation
+    between replays, must leave exactly the state the eager calls leave from the same starting point."""
+    from mineral_amd.common.normalizers import RunningMeanStd
+    spec = NETS['full']
+    N, T = mb // 8, 8
+    params = oracle_params(spec, 9)
+    model = make_model(spec, params)
+    buf = make_buffer(spec, N, T, mb)
+    _fill_training_buffer(spec, buf, N, T)
+    L = hip.lib()
+    P = model.param_count
+    ws = torch.empty(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
+    grads, m, v = (torch.zeros(P, device=DEV) for _ in range(3))
+    metrics = torch.zeros(hip.NMETRIC, dtype=torch.float64, device=DEV)
+    gnorm = torch.zeros(1, device=DEV)
+    scratch = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    rms = RunningMeanStd((spec['obs'],), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    obs2d = buf.storage_dict['obses']['obs'].reshape(N * T, -1)
+    bmean, bvar = obs2d.mean(0).contiguous(), obs2d.var(0, correction=1).contiguous()
+    mean_f, std_f = torch.empty(spec['obs'], device=DEV), torch.empty(spec['obs'], device=DEV)
+    chp = hip.PpoHp(0.2, 4.0, 0.0, 1e-4, 0, 0, 0)
+    c = rms.c_struct()
+
+    def step(s):
+        hip.check(L.mrl_rms_merge(c, hip.ptr(bmean), hip.ptr(bvar), float(mb), hip.ptr(mean_f), hip.ptr(std_f), s), 'merge')
+        hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, 0, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads),
+                                 hip.ptr(metrics), hip.ptr(ws), ws.numel(), s), 'grad')
+        hip.check(L.mrl_adam_step(hip.ptr(model.flat), hip.ptr(grads), hip.ptr(m), hip.ptr(v), P, 5e-4, 0.9, 0.999, 1e-5, 0.01, 1, 3, 0.5, 1.0,
+                                  hip.ptr(gnorm), hip.ptr(scratch), s), 'adam')
+
+    state = [model.flat, m, v, rms.running_mean, rms.running_var, rms.running_count, buf.storage_dict['mu'], buf.storage_dict['sigma']]
+    start = [t.clone() for t in state]
+
+    def restore():
+        for t, t0 in zip(state, start):
+            t.copy_(t0)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)                       # eager, also the warm-up before the capture
+    side.synchronize()
+    want = [t.clone() for t in state] + [metrics.clone(), gnorm.clone()]
+    assert all(bool(torch.isfinite(t).all()) for t in want)
+    restore()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        step(torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        restore()
+        metrics.zero_(); gnorm.zero_(); grads.fill_(float('nan'))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got = state + [metrics, gnorm]
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), f'replay {rep}: tensor {i} differs from the eager step'
+
+
+@pytest.mark.gpu
 def test_launch_structures_of_the_update_are_bit_identical():
     """Above 8192 rows mrl_ppo_grad lets the weight-gradient launches run beside the dgrad launch that reads the same dZ
     (any-order launches on the caller's stream; MRL_ANY_ORDER=0 keeps every launch in order), or, with MRL_TOWER_STREAMS=1,
