@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -350,9 +351,11 @@ extern "C" int mrl_debug_kblocks(unsigned long long* dst) {
 // A launch that does not wait for the launches before it on its stream (hipExtAnyOrderLaunch: the dispatch packet goes out
 // without the barrier bit): set around a launch whose inputs are complete once the launch before it has STARTED, so that
 // the two run side by side; the next ordinary launch waits for both.  Used for the weight-gradient launches of the backward
-// chain (each goes out right behind the dgrad launch that reads the same dZ) and the metrics reduction behind the slab
-// reduction: the same 2 % per update as separate streams with events (234.7 against 238.8 ms, streams 234.9) without
-// either.  MRL_ANY_ORDER=0 in the environment switches it off; it is off while kernels are being timed.
+// chain (each goes out right behind the dgrad launch that reads the same dZ) and the reduction of the heads' metric partials
+// (behind the first of those dgrad launches): the same 2 % per update as separate streams with events (234.7 against 238.8 ms,
+// streams 234.9) without either.  An any-order launch is never the last launch of an entry point: what the caller puts on the
+// stream next (an event record, a collective) must find an ordinary launch, which completes after everything before it, at the
+// end.  MRL_ANY_ORDER=0 in the environment switches it off; it is off while kernels are being timed.
 static thread_local bool g_any_order = false;
 static bool any_order_enabled() {
   static const int on = [] { const char* e = getenv("MRL_ANY_ORDER"); return e ? atoi(e) : 1; }();
@@ -1640,7 +1643,8 @@ static bool bwd_uses_planes(const mrl_net* net, const ParamLayout& L, int64_t mb
 static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
                               float* const* input_grad, hipStream_t s, bool planes_ready = false, hipStream_t wgrad_stream = nullptr,
-                              hipEvent_t* wgrad_events = nullptr) {
+                              hipEvent_t* wgrad_events = nullptr, const std::function<void(hipStream_t)>* beside_first = nullptr,
+                              bool* beside_first_done = nullptr) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
   // weight-gradient slabs of layer l (l == last + 1: the heads) on stream st
   auto wgrad_of = [&](int l, hipStream_t st) {
@@ -1678,10 +1682,19 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     if (hipEventRecord(e, s) == hipSuccess && hipStreamWaitEvent(wgrad_stream, e, 0) == hipSuccess) wgrad_of(l, wgrad_stream);
     else wgrad_of(l, s);   // ordering on s is always sufficient
   };
+  // beside_first: one more launch of the caller's that only needs what was complete before this call; it goes out any-order
+  // behind the first dgrad launch (never as the last launch of the chain: whatever follows an entry point on the stream --
+  // an event record, a collective -- must find an ordinary launch, which completes after everything before it, at the end)
+  bool hook_pending = beside_first != nullptr;
   auto flush_pending = [&](bool beside) {
     if (pending < 0) return;
     g_any_order = beside;
     wgrad_of(pending, s);
+    if (beside && hook_pending) {
+      (*beside_first)(s);
+      hook_pending = false;
+      if (beside_first_done) *beside_first_done = true;
+    }
     g_any_order = false;
     pending = -1;
   };
@@ -1935,6 +1948,18 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNELU>(p, dim3(hblocks, 1, towers), st);
     else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, towers), st);
   };
+  // the reduction of the heads' metric partials: any-order behind the first dgrad launch of the backward chain when that is
+  // on (launch_towers_bwd), otherwise an ordinary launch at the end
+  auto launch_metrics = [&](hipStream_t st) {
+    if (g_any_order)
+      hipExtLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, metric_part, hblocks, (double)mb,
+                            hp->critic_coef, hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+    else
+      hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, st, metric_part, hblocks, (double)mb, hp->critic_coef,
+                         hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
+  };
+  const std::function<void(hipStream_t)> metrics_hook = launch_metrics;
+  bool metrics_done = false;
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
   const bool planes = L.has_norm && mb > MRL_SMALL_M;
   const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
@@ -1957,17 +1982,11 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   } else {
     launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s, wpl);
     launch_heads(0, 2, s);
-    launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes);
+    launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes, nullptr, nullptr, &metrics_hook,
+                      &metrics_done);
     launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   }
-  {
-    if (any_order_enabled())   // beside the slab reduction launched just before it: it reads what the heads launch left long ago
-      hipExtLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, metric_part, hblocks, (double)mb,
-                            hp->critic_coef, hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
-    else
-      hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(192), 0, s, metric_part, hblocks, (double)mb, hp->critic_coef,
-                         hp->entropy_coef, hp->bounds_loss_coef, metrics_out);
-  }
+  if (!metrics_done) launch_metrics(s);
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
   return MRL_OK;
 }
