@@ -3,6 +3,7 @@
 #include "../../include/mineral_ppo.h"
 #include "gemm.hip.h"
 #include "split_bf16.hip.h"
+#include "chain.hip.h"
 
 #include <hip/hip_ext.h>
 #include <math.h>
@@ -151,6 +152,36 @@ constexpr int MRL_WGRAD_RESIDENT = 0;        // blocks per CU the split-K plan i
 
 struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 
+// Batches of at most MRL_SMALL_M rows run the row-local chain kernels and the one-launch weight gradient of chain.hip.h.
+// MRL_CHAIN in the environment (read once) is a bit mask for A/B measurements: 1 forward chain, 2 backward chain + weight
+// gradients; default 3.  The workspace layout (column-partial blocks, slab counts) follows bit 1, so it cannot change while a
+// process runs.
+constexpr int MRL_SMALL_M = 8192;
+static int chain_mask() {
+  static const int m = [] { const char* e = getenv("MRL_CHAIN"); return e ? atoi(e) : 3; }();
+  return m;
+}
+static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
+  return (chain_mask() & bit) != 0 && rows <= MRL_SMALL_M && net->n_layers <= CH_MAXL;
+}
+// 64 x 64 weight-gradient tiles of one tower (layers + head) and the row ranges they are split into: about 1,024 wave tasks
+// for two towers (one per SIMD: the launch keeps one block of four waves per CU), at least 64 rows each, whole multiples of 32 rows
+static int chain_wgrad_tiles(const mrl_net* net, const int* in_dim) {
+  int t = 0;
+  for (int l = 0; l < net->n_layers; ++l) t += (int)(cdiv(net->units[l], 64) * cdiv(in_dim[l], 64));
+  return t + (int)cdiv(net->units[net->n_layers - 1], 64);
+}
+static void chain_wgrad_split(const mrl_net* net, const int* in_dim, int64_t rows, int* nsplit, int* ksplit) {
+  static const int target = [] { const char* e = getenv("MRL_CHAIN_TASKS"); return e ? atoi(e) : 1024; }();
+  const int tiles = 2 * chain_wgrad_tiles(net, in_dim);
+  int64_t want = (target + tiles / 2) / tiles;
+  if (want < 1) want = 1;
+  int64_t ks = cdiv(cdiv(rows, want), 32) * 32;   // whole register groups of the weight-gradient kernel (32 rows)
+  if (ks < 64) ks = 64;
+  *ksplit = (int)ks;
+  *nsplit = (int)cdiv(rows, ks);
+}
+
 static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
   WgradPlan w;
   w.bm = (gm <= 32) ? 32 : 128;
@@ -171,6 +202,9 @@ static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
 struct Workspace {
   // offsets in floats from the workspace base
   int64_t xhat[2][MRL_MAX_LAYERS], rstd[2][MRL_MAX_LAYERS], dz[2][MRL_MAX_LAYERS];
+  int64_t dy[2][MRL_MAX_LAYERS];   // small batches: d loss / d LayerNorm output per layer (the weight-gradient launch sums its columns)
+  int64_t hact[2][MRL_MAX_LAYERS]; // small batches: activated layer outputs (operands of the weight gradients)
+  int64_t xnorm;                   // small batches: the normalised input rows
   int64_t seeds[2];
   int64_t colpart[2][MRL_MAX_LAYERS];
   int64_t slab[2][MRL_MAX_LAYERS], slab_h[2];
@@ -179,6 +213,7 @@ struct Workspace {
   int64_t small;         // misc: obs mean/std f32 (2*obs_dim), partial sums
   int64_t wplanes;       // the parameter vector split into three bf16 planes (wplane_stride elements each), refreshed by the launches that read it
   int64_t wplane_stride;
+  int64_t wblk_f[2][MRL_MAX_LAYERS], wblk_b[2][MRL_MAX_LAYERS];   // weights re-blocked for the chain kernels (forward / backward order)
   int64_t total;
   WgradPlan wp[MRL_MAX_LAYERS], wph;
   int rowblocks[MRL_MAX_LAYERS];
@@ -191,27 +226,46 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   int U = net->units[net->n_layers - 1];
   // activation tensors are padded to whole 128-row tiles: the LayerNorm epilogues read and write full tiles
   const int64_t rows_pad = cdiv(rows, 128) * 128;
+  const bool chain_bwd = chain_ok(net, rows, 2);
+  const bool chain_fb = chain_bwd && chain_ok(net, rows, 1);   // the forward chain stores what the weight gradients read
+  int ch_nsplit = 1, ch_ksplit = 64;
+  if (chain_bwd) chain_wgrad_split(net, L.in_dim, rows, &ch_nsplit, &ch_ksplit);
   for (int tw = 0; tw < 2; ++tw) {
     for (int l = 0; l < net->n_layers; ++l) {
       int u = net->units[l];
       w->xhat[tw][l] = o; o = align64(o + rows_pad * u);
       w->rstd[tw][l] = o; o = align64(o + rows_pad);
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
-      if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
+      if (chain_bwd) { w->dy[tw][l] = o; o = align64(o + rows_pad * u); }
+      if (chain_fb) { w->hact[tw][l] = o; o = align64(o + rows_pad * u); }
+      if (chain_bwd) w->rowblocks[l] = ch_nsplit;                                             // column partials per row range of the weight-gradient launch
+      else if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
       else w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
+      if (chain_bwd) { w->wp[l].nsplit = ch_nsplit; w->wp[l].ksplit = ch_ksplit; }
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
     }
     w->seeds[tw] = o; o = align64(o + rows * 32);
     w->wph = wgrad_plan(32, U, rows);
+    if (chain_bwd) { w->wph.nsplit = ch_nsplit; w->wph.ksplit = ch_ksplit; }
     w->slab_h[tw] = o; o = align64(o + (int64_t)w->wph.nsplit * 32 * U);
   }
+  w->xnorm = o;
+  if (chain_fb) o = align64(o + rows_pad * net->obs_dim);
   w->metric_part = o; o = align64(o + 2 * cdiv(rows, 128) * 2 * MRL_NMETRIC + 64);
   w->headb_part = o; o = align64(o + cdiv(rows, 128) * 64);
   w->small = o; o = align64(o + 4096 + 2 * (int64_t)net->obs_dim + 16 * cdiv(rows, 64));
   w->wplane_stride = align64(L.total);
   w->wplanes = o; o = align64(o + (6 * w->wplane_stride + 1) / 2);   // natural order, then k-blocked order
+  if (chain_ok(net, rows, 3)) {
+    for (int tw = 0; tw < 2; ++tw)
+      for (int l = 0; l < net->n_layers; ++l) {
+        const int u = net->units[l], kn = (l + 1 < net->n_layers) ? net->units[l + 1] : 32;
+        w->wblk_f[tw][l] = o; o = align64(o + (int64_t)u * ((L.in_dim[l] + 31) & ~31));
+        w->wblk_b[tw][l] = o; o = align64(o + (int64_t)((kn + 15) & ~15) * u);
+      }
+  }
   w->total = o;
 }
 
@@ -416,7 +470,6 @@ static void launch_gemm(const GemmP& p, dim3 grid, hipStream_t s, int resident =
 
 // full-row tiles, selected by the output width; batches of at most MRL_SMALL_M rows take 32-row tiles so that a
 // 2048-row minibatch still spreads over 64 blocks per tower instead of 16
-constexpr int MRL_SMALL_M = 8192;
 // waves per 32-row forward tile of the wide layers on small batches: 8 waves halve the staging and MFMA work of each wave
 // in a regime where a block's serial reduction loop, not the chip's throughput, sets the time
 constexpr int MRL_SMALL_WGN = 8;
@@ -606,9 +659,100 @@ static void launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s)
 }
 
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
+// LDS row stride of the chain kernels: every layer width and the (32-padded) input width, rounded up to 64 floats
+static int chain_ld(const mrl_net* net, int in_dim) {
+  int m = (in_dim + 31) & ~31;
+  for (int l = 0; l < net->n_layers; ++l) m = std::max(m, (int)net->units[l]);
+  return (m + 63) & ~63;
+}
+static size_t chain_lds_bytes(int ld) { return (size_t)(CH_RED + 2 * CH_ROWS * ld) * sizeof(float); }
+// the widest networks need a little more dynamic LDS than the 64 KB a kernel may ask for by default
+static void chain_allow_lds() {
+  static const bool once = [] {
+    const void* fns[] = {reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(chain_fwd_kernel<CH_PLAIN_ELU>),
+                         reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_SILU>),
+                         reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
+                         reinterpret_cast<const void*>(wgrad_small_kernel)};
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return true;
+  }();
+  (void)once;
+}
+// Weights of towers tw0 .. tw0+towers-1 into the workspace's re-blocked copies: forward order (W of every layer) and / or
+// backward order (W of the layer above, the head for the last layer).  One launch.
+static void launch_reblock(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, int tw0, int towers, bool fwd,
+                           bool bwd, hipStream_t s) {
+  ReblockP p;
+  memset(&p, 0, sizeof(p));
+  int piece = 0;
+  const int nl = net->n_layers;
+  for (int t = 0; t < towers; ++t) {
+    const int tw = tw0 + t;
+    for (int l = 0; l < nl; ++l) {
+      const int u = net->units[l];
+      if (fwd) {
+        ReblockDesc& d = p.d[p.nd++];
+        d.kind = 0; d.src = params + L.W[tw][l]; d.dst = ws + W.wblk_f[tw][l]; d.N = u; d.K = L.in_dim[l]; d.rows = u;
+        d.piece0 = piece;
+        piece += u * ((L.in_dim[l] + 31) & ~31) / 4;
+      }
+      if (bwd) {
+        ReblockDesc& d = p.d[p.nd++];
+        const bool last = l == nl - 1;
+        d.kind = 1; d.src = last ? params + L.Wh[tw] : params + L.W[tw][l + 1]; d.dst = ws + W.wblk_b[tw][l]; d.N = u;
+        d.K = last ? 32 : net->units[l + 1];
+        d.rows = last ? L.head_rows[tw] : net->units[l + 1];
+        d.piece0 = piece;
+        piece += ((d.K + 15) & ~15) * u / 4;
+      }
+    }
+  }
+  p.npieces = piece;
+  MRL_PROF_STREAM("mrl::reblock_kernel", s);
+  hipLaunchKernelGGL(reblock_kernel, dim3((unsigned)cdiv(piece, 256)), dim3(256), 0, s, p);
+}
+
+static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t rows,
+                             const float* obs_mean, const float* obs_std, float lo, float hi, int tw0, int towers, hipStream_t s, bool blocked_ready) {
+  if (!blocked_ready) launch_reblock(net, L, W, ws, params, tw0, towers, true, false, s);
+  ChainFwdP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.mean = obs_mean; p.stdv = obs_std; p.lo = lo; p.hi = hi;
+  p.M = (int)rows; p.in_dim = L.in_dim[0]; p.n_layers = net->n_layers;
+  const bool stores_act = chain_ok(net, rows, 2);   // the weight-gradient launch of the backward pass reads the activations from memory
+  p.ld = chain_ld(net, L.in_dim[0]);
+  p.rows_written = (int)(cdiv(rows, 128) * 128);   // the activation tensors are padded to whole 128-row tiles; all of it ends up finite
+  p.ln_eps = net->ln_eps;
+  for (int l = 0; l < net->n_layers; ++l) {
+    p.units[l] = net->units[l];
+    for (int t = 0; t < towers; ++t) {
+      const int tw = tw0 + t;
+      p.W[t][l] = ws + W.wblk_f[tw][l];
+      p.b[t][l] = params + L.b[tw][l];
+      p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
+      p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
+      p.xhat[t][l] = ws + W.xhat[tw][l];
+      p.rstd[t][l] = ws + W.rstd[tw][l];
+      p.hact[t][l] = stores_act ? ws + W.hact[tw][l] : nullptr;
+    }
+  }
+  p.xnorm = (stores_act && obs_mean) ? ws + W.xnorm : nullptr;
+  chain_allow_lds();
+  MRL_PROF_STREAM("mrl::chain_fwd_kernel", s);
+  const dim3 grid((unsigned)(p.rows_written / CH_ROWS), towers);
+  const size_t lds = chain_lds_bytes(p.ld);
+  if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(chain_fwd_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+  else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_fwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+  else hipLaunchKernelGGL(chain_fwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+}
+
 static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
                               const float* x, int64_t rows, const float* obs_mean, const float* obs_std, float lo, float hi,
-                              int tw0, int towers, hipStream_t s, const unsigned short* planes = nullptr) {
+                              int tw0, int towers, hipStream_t s, const unsigned short* planes = nullptr, bool blocked_ready = false) {
+  if (chain_ok(net, rows, 1)) {
+    launch_chain_fwd(net, L, W, ws, params, x, rows, obs_mean, obs_std, lo, hi, tw0, towers, s, blocked_ready);
+    return;
+  }
   for (int l = 0; l < net->n_layers; ++l) {
     GemmP p;
     memset(&p, 0, sizeof(p));
@@ -1627,6 +1771,101 @@ extern "C" int mrl_rms_normalize(const mrl_rms* rms, const float* x, float* y, i
   return MRL_OK;
 }
 
+// gradient with respect to the input of the first layer, one [mb][in_dim] matrix per tower: dX = dZ0 * W0
+static void launch_input_grad(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, int64_t mb, int tw0, int towers,
+                              float* const* input_grad, hipStream_t s) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  const int u0 = net->units[0], in0 = L.in_dim[0];
+  for (int k = 0; k < towers; ++k) {
+    const int tw = tw0 + k;
+    p.A[k] = ws + W.dz[tw][0];
+    p.B[k] = params + L.W[tw][0];
+    p.Kt[k] = u0; p.Nt[k] = in0;
+    p.out[k] = input_grad[k];
+  }
+  p.lda = u0; p.ldb = in0; p.ldo = in0;
+  p.M = (int)mb; p.N = in0; p.K = u0;
+  p.ksplit = u0; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = (int)cdiv(in0, 128);
+  p.n_groups = p.m_tiles; p.group_mode = 0;
+  launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+}
+
+// Backward of a small batch (chain.hip.h): the dgrad chain of all layers in one launch, then (wgrad) every weight gradient of
+// the towers in one launch.  Same buffers as the per-layer launches: dZ per layer, column partials per 16-row block, slabs.
+static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
+                             const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad, hipStream_t s,
+                             bool blocked_ready) {
+  const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  if (!blocked_ready) launch_reblock(net, L, W, ws, params, tw0, towers, false, true, s);
+  {
+    ChainBwdP p;
+    memset(&p, 0, sizeof(p));
+    p.M = (int)mb; p.n_layers = nl; p.ld = chain_ld(net, 32);
+    for (int l = 0; l < nl; ++l) {
+      p.units[l] = net->units[l];
+      for (int t = 0; t < towers; ++t) {
+        const int tw = tw0 + t;
+        p.Wn[t][l] = ws + W.wblk_b[tw][l];
+        p.xhat[t][l] = ws + W.xhat[tw][l];
+        p.rstd[t][l] = ws + W.rstd[tw][l];
+        p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
+        p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
+        p.dz[t][l] = ws + W.dz[tw][l];
+        p.dy[t][l] = L.has_norm ? ws + W.dy[tw][l] : nullptr;
+      }
+    }
+    for (int t = 0; t < towers; ++t) p.seeds[t] = ws + W.seeds[tw0 + t];
+    chain_allow_lds();
+    MRL_PROF_STREAM("mrl::chain_bwd_kernel", s);
+    const dim3 grid((unsigned)cdiv(mb, CH_ROWS), towers);
+    const size_t lds = chain_lds_bytes(p.ld);
+    if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+    else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+    else hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+  }
+  if (!wgrad) return;
+  WgradSmallP q;
+  memset(&q, 0, sizeof(q));
+  q.M = (int)mb; q.nsplit = W.wph.nsplit; q.ksplit = W.wph.ksplit; q.lo = clamp_lo; q.hi = clamp_hi;
+  // with the forward chain the operands were stored ready-made (activated outputs, normalised input); otherwise they are
+  // rebuilt from x-hat / the raw input by the operand prologue
+  const bool ready = chain_ok(net, mb, 1);
+  const int pro_hidden = ready ? PRO_NONE : (L.has_norm ? (net->tower_kind == TOWER_LAYERNORM_ELU ? PRO_LNELU : PRO_LNSILU) : PRO_ELU);
+  int task = 0;
+  for (int t = 0; t < towers; ++t) {
+    const int tw = tw0 + t;
+    for (int l = last + 1; l >= 0; --l) {
+      WgDesc& d = q.d[q.nd++];
+      const bool head = l == last + 1;
+      d.u = head ? 32 : net->units[l];
+      d.in = head ? U : L.in_dim[l];
+      d.ldz = d.u; d.slab_rows = d.u;
+      d.dz = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
+      d.xin = (l == 0) ? ((ready && obs_mean) ? ws + W.xnorm : x) : (ready ? ws + W.hact[tw][l - 1] : ws + W.xhat[tw][l - 1]);
+      d.pro = (l == 0) ? ((obs_mean && !ready) ? PRO_NORM : PRO_NONE) : pro_hidden;
+      d.pro0 = (l == 0) ? obs_mean : (L.has_norm ? params + L.g[tw][l - 1] : nullptr);
+      d.pro1 = (l == 0) ? obs_std : (L.has_norm ? params + L.be[tw][l - 1] : nullptr);
+      d.slab = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
+      if (!head) {   // column sums of this layer: d bias from dZ, d gamma / d beta from dY and x-hat
+        d.colpart = ws + W.colpart[tw][l];
+        d.dy = L.has_norm ? ws + W.dy[tw][l] : nullptr;
+        d.xout = L.has_norm ? ws + W.xhat[tw][l] : nullptr;
+      }
+      d.tiles_n = (int)cdiv(d.in, 64);
+      d.tiles = (int)cdiv(d.u, 64) * d.tiles_n;
+      d.task0 = task;
+      task += d.tiles * q.nsplit;
+    }
+  }
+  q.ntasks = task;
+  MRL_PROF_STREAM("mrl::wgrad_small_kernel", s);
+  // 84 KB of (unused) dynamic LDS keep the blocks (8 waves: 4 tasks, two waves each) at one per CU: a second block would share
+  // the matrix cores and take twice as long while other CUs sit idle
+  static const int wg_lds = [] { const char* e = getenv("MRL_CHAIN_WGLDS"); return e ? atoi(e) : 84 * 1024; }();
+  hipLaunchKernelGGL(wgrad_small_kernel, dim3((unsigned)cdiv(task, 4)), dim3(512), wg_lds, s, q);
+}
+
 // Backward of `towers` towers (tower indices tw0 .. tw0+towers-1 of the workspace / layout) from the head seeds
 // ws[W.seeds[tw]] ([rows][32], zero padded): dgrad chain with the LayerNorm/SiLU backward of every layer, then (wgrad)
 // the partial weight-gradient slabs of every layer and head, and (input_grad) the gradient with respect to the first
@@ -1646,6 +1885,12 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
                               hipEvent_t* wgrad_events = nullptr, const std::function<void(hipStream_t)>* beside_first = nullptr,
                               bool* beside_first_done = nullptr) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  if (chain_ok(net, mb, 2)) {
+    // small batches: the whole dgrad chain in one launch, every weight gradient in a second one
+    launch_chain_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw0, towers, wgrad, s, planes_ready);
+    if (input_grad) launch_input_grad(net, L, W, ws, params, mb, tw0, towers, input_grad, s);
+    return;
+  }
   // weight-gradient slabs of layer l (l == last + 1: the heads) on stream st
   auto wgrad_of = [&](int l, hipStream_t st) {
     GemmP p;
@@ -1781,21 +2026,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
 
   // ---- gradient with respect to the input of the first layer: dX = dZ0 * W0 ----------------------------------------
   if (input_grad) {
-    GemmP p;
-    memset(&p, 0, sizeof(p));
-    const int u0 = net->units[0], in0 = L.in_dim[0];
-    for (int k = 0; k < towers; ++k) {
-      const int tw = tw0 + k;
-      p.A[k] = ws + W.dz[tw][0];
-      p.B[k] = params + L.W[tw][0];
-      p.Kt[k] = u0; p.Nt[k] = in0;
-      p.out[k] = input_grad[k];
-    }
-    p.lda = u0; p.ldb = in0; p.ldo = in0;
-    p.M = (int)mb; p.N = in0; p.K = u0;
-    p.ksplit = u0; p.m_tiles = (int)cdiv(mb, 128); p.n_tiles = (int)cdiv(in0, 128);
-    p.n_groups = p.m_tiles; p.group_mode = 0;
-    launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
+    launch_input_grad(net, L, W, ws, params, mb, tw0, towers, input_grad, s);
     flush_pending(true);
   }
   flush_pending(false);   // the first layer's weight gradient when no launch is left to run beside
@@ -1963,6 +2194,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
   const bool planes = L.has_norm && mb > MRL_SMALL_M;
   const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
+  // small batches: the weights re-blocked for the chain kernels, once per call for the forward and the backward pass
+  const bool ch_f = chain_ok(net, mb, 1), ch_b = chain_ok(net, mb, 2);
+  if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s);
   if (tower_streams(mb)) {
     SideStream* ss = nullptr;
     if (int rc = side_stream(&ss)) return rc;
@@ -1980,9 +2214,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     }
     if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "join of the tower streams failed");
   } else {
-    launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s, wpl);
+    launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s, wpl, true);
     launch_heads(0, 2, s);
-    launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes, nullptr, nullptr, &metrics_hook,
+    launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes || ch_b, nullptr, nullptr, &metrics_hook,
                       &metrics_done);
     launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
   }
