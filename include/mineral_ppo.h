@@ -219,6 +219,19 @@ int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
                   float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream);
 
+/* One whole optimizer step of PPO.train_epoch on one minibatch (ppo.py:254-313) for callers without a gradient
+ * all-reduce between backward and optimizer.step(): exactly mrl_rms_merge (when obs_rms != NULL) + mrl_ppo_grad +
+ * mrl_adam_step(grad_scale = 1) on the same arguments, and bit-identical to those three calls, but the library is free
+ * to fold their launches into each other (the statistics merge rides in the first launch of the step, the gradient
+ * norm is taken while the gradient vector is written).  obs_rms == NULL: no merge; obs_mean_f32 / obs_std_f32 are
+ * then inputs (both NULL = no input normalisation).  count of the Adam vectors = mrl_param_count(net). */
+int mrl_ppo_step(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t row0,
+                 int64_t mb, const mrl_rms* obs_rms, const float* batch_mean, const float* batch_var,
+                 double batch_count, float* obs_mean_f32, float* obs_std_f32, float clamp_lo, float clamp_hi,
+                 float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes, float* exp_avg,
+                 float* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int32_t adamw, int64_t step, float max_norm, float* gnorm_out, void* scratch, void* stream);
+
 /* Benchmark support, no counterpart in the reference: time the MFMA GEMM launches with HIP events on the stream
  * they are issued to.  mode 0 = off (default), 1 = every GEMM instantiation, 2 = only the instantiation that has
  * accumulated the most time so far (call after a mode-1 warm-up; with nothing timed since the last call the choice of the last

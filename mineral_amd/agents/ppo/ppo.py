@@ -306,6 +306,7 @@ class PPO(Agent):
             obs_rms = self.obs_rms['obs'].c_struct()
             lo, hi = obs_rms.clamp_lo, obs_rms.clamp_hi
         else:
+            obs_rms = None
             lo, hi = 0.0, 0.0
         adamw = 1 if self.optim_type == 'AdamW' else 0
         max_norm = float(self.max_grad_norm) if self.truncate_grads else 0.0
@@ -316,6 +317,21 @@ class PPO(Agent):
             self.mini_epoch += 1
             k0 = k
             for i in range(n_mb):
+                if self._dist is None:
+                    # no collective between backward and optimizer.step(): the whole step in one call (bit-identical to the three
+                    # calls of the other branch)
+                    self.optim_step += 1
+                    _hip.check(L.mrl_ppo_step(net, _hip.ptr(flat), self.hp, buf.c, i * mb, mb, obs_rms,
+                                              _hip.ptr(self._mb_mean[i]) if obs_rms is not None else None,
+                                              _hip.ptr(self._mb_var[i]) if obs_rms is not None else None, count,
+                                              _hip.ptr(self._obs_mean_f) if obs_rms is not None else None,
+                                              _hip.ptr(self._obs_std_f) if obs_rms is not None else None, lo, hi,
+                                              _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(),
+                                              _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), self._optim_lr, self.betas[0], self.betas[1],
+                                              self.adam_eps, self.weight_decay, adamw, self.optim_step, max_norm,
+                                              _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_ppo_step')
+                    k += 1
+                    continue
                 if self.normalize_input:
                     _hip.check(L.mrl_rms_merge(obs_rms, _hip.ptr(self._mb_mean[i]), _hip.ptr(self._mb_var[i]), count,
                                                _hip.ptr(self._obs_mean_f), _hip.ptr(self._obs_std_f), s), 'mrl_rms_merge')

@@ -329,13 +329,11 @@ __device__ __forceinline__ void chain_fwd_layer(const ChainFwdP& p, int tw, int 
   if (p.hact[tw][l]) ch_copy_out<N>(tid, hout, ld, p.hact[tw][l], m0, p.rows_written);
 }
 
+// The forward chain of the block's 16 rows.  On return `cur` is the tile with the last layer's activated output, `nxt` the one with
+// its x-hat (both still being copied to memory by some waves: a barrier must come before either is overwritten).
 template <int KIND>
-__global__ __launch_bounds__(64 * CH_WAVES) void chain_fwd_kernel(const ChainFwdP p) {
-  extern __shared__ __attribute__((aligned(16))) float ch_lds[];
-  float* red = ch_lds;
-  float* cur = ch_lds + CH_RED;
-  float* nxt = cur + CH_ROWS * p.ld;
-  const int tid = threadIdx.x, tw = blockIdx.y, m0 = blockIdx.x * CH_ROWS;
+__device__ __forceinline__ void chain_fwd_body(const ChainFwdP& p, float* red, float*& cur, float*& nxt, int tw, int m0) {
+  const int tid = threadIdx.x;
   f32x4 wpre0[8];
   CH_STAMP(0);
   chain_fwd_prefetch(p, tw, 0, p.in_dim, wpre0);
@@ -373,6 +371,14 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_fwd_kernel(const ChainFwd
     float* t = cur; cur = nxt; nxt = t;
     K = p.units[l];
   }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64 * CH_WAVES) void chain_fwd_kernel(const ChainFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float ch_lds[];
+  float* cur = ch_lds + CH_RED;
+  float* nxt = cur + CH_ROWS * p.ld;
+  chain_fwd_body<KIND>(p, ch_lds, cur, nxt, blockIdx.y, blockIdx.x * CH_ROWS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -559,6 +565,24 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
   if constexpr (HAS_NORM) ch_copy_out<N>(tid, zin, ld, p.dy[tw][l], m0, 0x7fffffff);
 }
 
+// The backward chain of the block's 16 rows from the head seeds in tile `cur` ([16][32], swizzled like every tile); wpre0 holds the
+// first register group of the last layer (chain_bwd_prefetch).
+template <int KIND>
+__device__ __forceinline__ void chain_bwd_body(const ChainBwdP& p, float* red, float* cur, float* nxt, int tw, int m0, float (&wpre0)[32]) {
+  int K = 32;
+  for (int l = p.n_layers - 1; l >= 0; --l) {
+    switch (p.units[l]) {
+      case 512: chain_bwd_layer<512, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+      case 256: chain_bwd_layer<256, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+      case 128: chain_bwd_layer<128, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+      case 64: chain_bwd_layer<64, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+      default: chain_bwd_layer<32, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+    }
+    float* t = cur; cur = nxt; nxt = t;
+    K = p.units[l];
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64 * CH_WAVES) void chain_bwd_kernel(const ChainBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ch_lds[];
@@ -577,18 +601,252 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_bwd_kernel(const ChainBwd
     *reinterpret_cast<f32x4*>(cur + ch_off(r, ch, p.ld)) = v;
   }
   __syncthreads();
-  int K = 32;
-  for (int l = p.n_layers - 1; l >= 0; --l) {
-    switch (p.units[l]) {
-      case 512: chain_bwd_layer<512, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 256: chain_bwd_layer<256, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 128: chain_bwd_layer<128, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 64: chain_bwd_layer<64, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      default: chain_bwd_layer<32, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+  chain_bwd_body<KIND>(p, red, cur, nxt, tw, m0, wpre0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PPO minibatch step: forward chain, heads with the losses and their derivatives, backward chain -- one launch.  Every step is
+// local to a batch row, so the block that owns 16 rows never has to leave its CU between the passes: the last layer's output
+// is still in LDS when the heads multiply it, and the seeds d loss / d head go to the backward chain through LDS.
+// (mineral/agents/ppo/ppo.py:277-303 on mineral/agents/ppo/models.py:93-107.)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ChainPpoP {
+  ChainFwdP f;
+  ChainBwdP b;
+  HeadsP h;                    // metric_part [blocks][2][MRL_NMETRIC] and headb_part [blocks][2][32] are per 16-row block here
+  const float* Wh[2];          // head weights re-blocked in forward order as a [32][U] matrix (rows past the head's outputs zero)
+  const float* bh[2];
+  int head_n[2];               // head outputs per tower (2 A or A for the actor, 1 for the critic)
+};
+
+constexpr int CH_TS = 33;                                                       // row stride of the head-output tile
+constexpr int CH_HEADS_F = CH_ROWS * CH_TS + 16 * MRL_NMETRIC * 2 + 16 * 32;    // floats of LDS behind the two activation tiles
+
+// head pre-activations of the block's rows: T[row][col] = h[row] . Wh[col] + bias[col], 32 columns (zero weights past the head)
+__device__ __forceinline__ void chain_heads_gemm(const float* WhB, const float* bias, int Nv, int K, const float* hin, int ld, float* T) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+  if (wave >= 2) return;
+  const int steps = K >> 5;   // layer widths are multiples of 32
+  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WhB), 0, 32 * steps * 32 * 4, 0x00020000);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < steps; s0 += 4) {
+    f32x4 w[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int soff = (wave * steps + min(s0 + u, steps - 1)) * 2048;
+      w[2 * u] = ch_load16(rsW, lane * 16, soff);
+      w[2 * u + 1] = ch_load16(rsW, lane * 16, soff + 1024);
     }
-    float* t = cur; cur = nxt; nxt = t;
-    K = p.units[l];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int step = s0 + u;
+      if (step < steps) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(hin + ch_off(r16, step * 8 + g, ld));
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(hin + ch_off(r16, step * 8 + 4 + g, ld));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = ch_mfma(w[2 * u][j], x0[j], acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = ch_mfma(w[2 * u + 1][j], x1[j], acc);
+      }
+    }
   }
+  const int c = 16 * wave + 4 * g;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) T[r16 * CH_TS + c + e] = acc[e] + (c + e < Nv ? bias[c + e] : 0.f);
+}
+
+// Losses, metrics and seeds of the block's 16 rows from the head outputs T.  Actor blocks: wave w < 4 takes rows 4 w .. 4 w + 3,
+// one per 16-lane group, lane j of the group action j.  Critic blocks: lane l < 16 of wave 0 takes row l.  The seed rows go to the
+// LDS tile `seedt` (the input of the backward chain; rows past the batch zero) and to memory (the heads' weight gradient).
+__device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int m0, int M, const float* T, float* seedt, int ld, double* red2,
+                                                  float* csum) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int A = hp.act_dim;
+  auto fexp = [](float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); };
+  auto flog = [](float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); };
+  auto frcp = [](float x) { return __builtin_amdgcn_rcpf(x); };
+  auto ftanh = [&](float x) {
+    const float e = __builtin_amdgcn_exp2f(2.88539008177792681472f * fabsf(x));
+    return copysignf(1.0f - 2.0f * frcp(1.0f + e), x);
+  };
+  if (tw == 0) {
+    if (wave >= 4) return;
+    // mineral/agents/ppo/models.py:93-107,140-151 and mineral/agents/ppo/ppo.py:277-303
+    const int g = lane >> 4, j = lane & 15, lr = wave * 4 + g, row = m0 + lr;
+    const bool jv = j < A, rv = row < M;
+    const int rowc = rv ? row : 0;
+    const float a = jv ? hp.actions[(int64_t)rowc * A + j] : 0.f;
+    const float omu = jv ? hp.mu[(int64_t)rowc * A + j] : 0.f;
+    const float osg = jv ? hp.sigma[(int64_t)rowc * A + j] : 1.f;
+    const float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
+    const float o = T[lr * CH_TS + j];
+    const float ls = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : T[lr * CH_TS + ((A + j) & 31)];
+    float mu, sg = 0.f, sigma;
+    if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
+      mu = ftanh(o);
+      sg = sigmoid_fast(ls + 2.0f);
+      sigma = (hp.maxstd - hp.minstd) * sg + hp.minstd;
+    } else {                                   // mineral/nets/dist.py:32-34
+      mu = o;
+      sigma = fexp(ls);
+    }
+    if (!jv) { mu = 0.f; sigma = 1.f; }
+    const float logsig = flog(sigma), rsig = frcp(sigma);
+    const float d = a - mu, rvar = rsig * rsig;
+    float nl = jv ? (d * d) * (0.5f * rvar) + logsig + MRL_LOG_SQRT_2PI : 0.f;
+    float ent = jv ? 0.5f + MRL_LOG_SQRT_2PI + logsig : 0.f;
+    float bl = 0.f, dbl = 0.f;
+    if (jv) {
+      if (hp.bounds_type == 0) {               // 'bound' (ppo.py:480-484)
+        const float hi = fmaxf(mu - 1.1f, 0.f), lo = fminf(mu + 1.1f, 0.f);
+        bl = lo * lo + hi * hi;
+        dbl = 2.0f * hi + 2.0f * lo;
+      } else {                                 // 'reg' (ppo.py:485-487)
+        bl = mu * mu;
+        dbl = 2.0f * mu;
+      }
+    }
+    float kl = 0.f;
+    if (jv) {                                  // ppo.py:492-498, p0 = new, p1 = stored
+      const float dm = omu - mu;
+      kl = flog(osg * rsig + 1e-5f) + (sigma * sigma + dm * dm) * (0.5f * frcp(osg * osg + 1e-5f)) - 0.5f;
+    }
+    nl = group_sum16(nl);
+    ent = group_sum16(ent);
+    bl = group_sum16(bl);
+    kl = group_sum16(kl);
+    const float ratio = fexp(oldnl - nl);                  // ppo.py:455
+    const float lo_r = 1.0f - hp.e_clip, hi_r = 1.0f + hp.e_clip;
+    float rc = fminf(fmaxf(ratio, lo_r), hi_r);
+    float inr = (ratio >= lo_r && ratio <= hi_r) ? 1.0f : 0.0f;      // d clamp / d ratio
+    if (hp.smooth_clamp) {                                            // ppo.py:449-450: a sigmoid between the bounds
+      const float sc = frcp(1.0f + fexp((-(ratio - lo_r) * frcp(hi_r - lo_r) + 0.5f) * 4.0f));
+      rc = sc * (hi_r - lo_r) + lo_r;
+      inr = 4.0f * sc * (1.0f - sc);
+    }
+    const float x1 = -(adv * ratio), x2 = -(adv * rc);
+    const float al = fmaxf(x1, x2);
+    const float dratio = (x1 > x2) ? -adv : (x1 < x2) ? -adv * inr : 0.5f * (-adv) + 0.5f * (-adv * inr);
+    const float dnl = hp.inv_mb * dratio * (-ratio);
+    const float dmu = dnl * (-d * rvar) + hp.bounds_coef * hp.inv_mb * dbl;
+    const float dsig = dnl * (-(d * d) * (rvar * rsig) + rsig) - hp.entropy_coef * hp.inv_mb * rsig;
+    float s_mu, s_ls;
+    if (hp.dist_type == DIST_DREAMERV3) {
+      s_mu = dmu * (1.0f - mu * mu);
+      s_ls = dsig * (hp.maxstd - hp.minstd) * sg * (1.0f - sg);
+    } else {
+      s_mu = dmu;
+      s_ls = dsig * sigma;
+    }
+    if (!rv || !jv) { s_mu = 0.f; s_ls = 0.f; }
+    auto seed_at = [&](int c) -> float& { return seedt[ch_off(lr, c >> 2, ld) + (c & 3)]; };
+    if (jv) {
+      seed_at(j) = s_mu;
+      seed_at(A + j) = s_ls;
+    }
+    for (int c = 2 * A + j; c < 32; c += 16) seed_at(c) = 0.f;
+    if (rv) {
+      float* sd = hp.seeds[0] + (int64_t)row * 32;
+      if (jv) {
+        sd[j] = s_mu;
+        sd[A + j] = s_ls;
+        hp.mu[(int64_t)row * A + j] = mu;                  // experience.py:83-87 write-back
+        hp.sigma[(int64_t)row * A + j] = sigma;
+      }
+      for (int c = 2 * A + j; c < 32; c += 16) sd[c] = 0.f;
+    }
+    const int part = wave * 4 + g;
+    if (jv) {
+      csum[part * 32 + j] = s_mu;
+      csum[part * 32 + A + j] = s_ls;
+    }
+    if (j == 0 && rv) {
+      double* m = red2 + part * MRL_NMETRIC;
+      m[0] = (double)al; m[1] = (double)ent; m[2] = (double)bl; m[3] = (double)kl;
+      m[4] = (fabsf(ratio - 1.0f) > hp.e_clip) ? 1.0 : 0.0;
+    }
+  } else {
+    if (wave >= 1) return;
+    // critic: column 0 of the tile is the value (models.py:147-149); ppo.py:466-473
+    const int lr = lane & 15, row = m0 + lr;
+    const bool rv = row < M, mine = rv && lane < 16;
+    const int rowc = rv ? row : 0;
+    const float v = T[lr * CH_TS];
+    const float ret = hp.returns[rowc], vp = hp.value_preds[rowc];
+    const float e1 = v - ret;
+    float cl = e1 * e1, dv = 2.0f * e1;
+    if (hp.clip_value_loss) {
+      const float dvp = v - vp;
+      const float vc = vp + fminf(fmaxf(dvp, -hp.e_clip), hp.e_clip);
+      const float e2 = vc - ret;
+      const float c2v = e2 * e2;
+      const float in2 = (dvp >= -hp.e_clip && dvp <= hp.e_clip) ? 1.0f : 0.0f;
+      const float d2 = 2.0f * e2 * in2;
+      dv = (cl > c2v) ? dv : (cl < c2v) ? d2 : 0.5f * dv + 0.5f * d2;
+      cl = fmaxf(cl, c2v);
+    }
+    const float s_v = mine ? hp.inv_mb * 0.5f * hp.critic_coef * dv : 0.f;   // ppo.py:285
+    if (lane < 16) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f}, first = {s_v, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) *reinterpret_cast<f32x4*>(seedt + ch_off(lr, ch, ld)) = ch == 0 ? first : z;
+      if (rv) {
+        f32x4* sd = reinterpret_cast<f32x4*>(hp.seeds[1] + (int64_t)row * 32);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) sd[ch] = ch == 0 ? first : z;
+      }
+    }
+    const double dr = mine ? (double)ret - (double)v : 0.0;
+    double q[5] = {mine ? (double)cl : 0.0, dr, dr * dr, mine ? (double)ret : 0.0, mine ? (double)ret * ret : 0.0};
+    float cs = s_v;
+#pragma unroll
+    for (int msk = 1; msk < 16; msk <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) q[i] += __shfl_xor(q[i], msk);
+      cs += __shfl_xor(cs, msk);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) red2[5 + i] = q[i];
+      csum[0] = cs;
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64 * CH_WAVES) void ppo_chain_kernel(const ChainPpoP p) {
+  extern __shared__ __attribute__((aligned(16))) float ch_lds[];
+  float* red = ch_lds;
+  float* cur = ch_lds + CH_RED;
+  float* nxt = cur + CH_ROWS * p.f.ld;
+  float* T = nxt + CH_ROWS * p.f.ld;
+  double* red2 = reinterpret_cast<double*>(T + CH_ROWS * CH_TS);   // [16 (wave, group) partials][MRL_NMETRIC]
+  float* csum = reinterpret_cast<float*>(red2 + 16 * MRL_NMETRIC);  // [16][32] seed columns (head-bias gradients)
+  const int tid = threadIdx.x, tw = blockIdx.y, m0 = blockIdx.x * CH_ROWS, ld = p.f.ld;
+  chain_fwd_body<KIND>(p.f, red, cur, nxt, tw, m0);
+  if (m0 >= p.f.M) return;   // blocks of padding rows (the activation tensors are kept finite up to a whole 128-row tile): forward only
+  float wpre0[32];
+  chain_bwd_prefetch(p.b, tw, p.b.n_layers - 1, 32, wpre0);
+  for (int i = tid; i < 16 * MRL_NMETRIC; i += 64 * CH_WAVES) red2[i] = 0.0;
+  csum[tid] = 0.f;
+  chain_heads_gemm(p.Wh[tw], p.bh[tw], p.head_n[tw], p.f.units[p.f.n_layers - 1], cur, ld, T);
+  __syncthreads();   // T is complete, and every wave has finished copying the last layer's tiles to memory
+  chain_heads_train(p.h, tw, m0, p.f.M, T, nxt, ld, red2, csum);
+  __syncthreads();
+  if (tid < MRL_NMETRIC) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red2[w * MRL_NMETRIC + tid];
+    p.h.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
+  } else if (tid >= 64 && tid < 96) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += csum[w * 32 + tid - 64];
+    p.h.headb_part[((int64_t)blockIdx.x * 2 + tw) * 32 + tid - 64] = s;
+  }
+  chain_bwd_body<KIND>(p.b, red, nxt, cur, tw, m0, wpre0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -600,11 +858,36 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_bwd_kernel(const ChainBwd
 //                                                               =  Wn[16 step + 4 g + s][16 J nw + J i + jj]
 // Rows / columns past the matrix are zeros.
 // ---------------------------------------------------------------------------------------------------------------------
-struct ReblockDesc { const float* src; float* dst; int kind, N, K, rows, piece0; };   // K: columns of src (fwd) ; rows: valid rows of src (bwd)
-constexpr int RB_MAXDESC = 16;
-struct ReblockP { ReblockDesc d[RB_MAXDESC]; int nd, npieces; };
+struct ReblockDesc { const float* src; float* dst; int kind, N, K, rows, piece0; };   // K: columns of src (fwd); rows: valid rows of src
+constexpr int RB_MAXDESC = 18;   // (4 layers x 2 orders + head) x 2 towers
+// Merge of a batch's moments into the running statistics of the observations (mineral/common/normalizers.py:44-55), and the
+// fp32 mean / standard deviation the kernels normalise with.  One block; the shared count is read before anyone writes it.
+struct RmsMergeArgs { double *mean, *var, *count; const float *bmean, *bvar; double bcount; int n; float eps; float *mean_f, *std_f; };
+__device__ __forceinline__ void rms_merge_body(const RmsMergeArgs& a) {
+  const double cnt = a.count[0];
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+    const double m = a.mean[i], v = a.var[i];
+    const double delta = (double)a.bmean[i] - m;
+    const double tot = cnt + a.bcount;
+    const double nm = m + delta * a.bcount / tot;
+    const double m2 = v * cnt + (double)a.bvar[i] * a.bcount + delta * delta * cnt * a.bcount / tot;
+    const double nv = m2 / tot;
+    a.mean[i] = nm;
+    a.var[i] = nv;
+    if (a.mean_f) a.mean_f[i] = (float)nm;
+    if (a.std_f) a.std_f[i] = sqrtf((float)nv + a.eps);
+  }
+  if (threadIdx.x == 0) a.count[0] = cnt + a.bcount;
+}
+
+struct ReblockP { ReblockDesc d[RB_MAXDESC]; int nd, npieces, has_merge; RmsMergeArgs merge; };
 
 __global__ __launch_bounds__(256) void reblock_kernel(const ReblockP p) {
+  if (p.has_merge && blockIdx.x == gridDim.x - 1) {   // one more block: the statistics merge of the step
+    rms_merge_body(p.merge);
+    return;
+  }
   const int piece = blockIdx.x * 256 + threadIdx.x;
   if (piece >= p.npieces) return;
   int di = 0;
@@ -618,7 +901,7 @@ __global__ __launch_bounds__(256) void reblock_kernel(const ReblockP p) {
     const int r = lp & 15, g = (lp >> 4) & 3, h = (lp >> 6) & 1, ts = lp >> 7;
     const int tile = ts / steps, step = ts - tile * steps;
     const int k = 32 * step + 16 * h + 4 * g;
-    if (k < d.K) v = *reinterpret_cast<const f32x4*>(d.src + (int64_t)(16 * tile + r) * d.K + k);
+    if (k < d.K && 16 * tile + r < d.rows) v = *reinterpret_cast<const f32x4*>(d.src + (int64_t)(16 * tile + r) * d.K + k);
   } else {
     const int J = d.N >= 512 ? 4 : (d.N >= 256 ? 2 : 1);
     const int f = lp * 4;                       // first float of the piece

@@ -154,11 +154,11 @@ struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 
 // Batches of at most MRL_SMALL_M rows run the row-local chain kernels and the one-launch weight gradient of chain.hip.h.
 // MRL_CHAIN in the environment (read once) is a bit mask for A/B measurements: 1 forward chain, 2 backward chain + weight
-// gradients; default 3.  The workspace layout (column-partial blocks, slab counts) follows bit 1, so it cannot change while a
+// gradients, 4 (with both) forward, heads and backward of a PPO step in one launch; default 7.  The workspace layout (column-partial blocks, slab counts) follows bit 1, so it cannot change while a
 // process runs.
 constexpr int MRL_SMALL_M = 8192;
 static int chain_mask() {
-  static const int m = [] { const char* e = getenv("MRL_CHAIN"); return e ? atoi(e) : 3; }();
+  static const int m = [] { const char* e = getenv("MRL_CHAIN"); return e ? atoi(e) : 7; }();
   return m;
 }
 static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
@@ -209,11 +209,13 @@ struct Workspace {
   int64_t colpart[2][MRL_MAX_LAYERS];
   int64_t slab[2][MRL_MAX_LAYERS], slab_h[2];
   int64_t metric_part;   // doubles, 8-byte aligned
-  int64_t headb_part;    // [rows/128][2][32] column sums of the head seeds (bias gradients)
+  int64_t headb_part;    // [row blocks][2][32] column sums of the head seeds (bias gradients); row blocks of 128 rows, or of 16 (chain kernels)
   int64_t small;         // misc: obs mean/std f32 (2*obs_dim), partial sums
+  int64_t norm_part;     // up to 512 doubles: squared-norm partials of the flat gradient (reduce_flat_kernel)
   int64_t wplanes;       // the parameter vector split into three bf16 planes (wplane_stride elements each), refreshed by the launches that read it
   int64_t wplane_stride;
   int64_t wblk_f[2][MRL_MAX_LAYERS], wblk_b[2][MRL_MAX_LAYERS];   // weights re-blocked for the chain kernels (forward / backward order)
+  int64_t wblk_h[2];     // head weights re-blocked in forward order ([32][U], zero rows past the head's outputs)
   int64_t total;
   WgradPlan wp[MRL_MAX_LAYERS], wph;
   int rowblocks[MRL_MAX_LAYERS];
@@ -253,9 +255,11 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   }
   w->xnorm = o;
   if (chain_fb) o = align64(o + rows_pad * net->obs_dim);
-  w->metric_part = o; o = align64(o + 2 * cdiv(rows, 128) * 2 * MRL_NMETRIC + 64);
-  w->headb_part = o; o = align64(o + cdiv(rows, 128) * 64);
+  const int64_t hb = chain_fb ? cdiv(rows, CH_ROWS) : cdiv(rows, 128);   // row blocks of the kernel that evaluates the heads
+  w->metric_part = o; o = align64(o + 2 * hb * 2 * MRL_NMETRIC + 64);
+  w->headb_part = o; o = align64(o + hb * 64);
   w->small = o; o = align64(o + 4096 + 2 * (int64_t)net->obs_dim + 16 * cdiv(rows, 64));
+  w->norm_part = o; o = align64(o + 1024);
   w->wplane_stride = align64(L.total);
   w->wplanes = o; o = align64(o + (6 * w->wplane_stride + 1) / 2);   // natural order, then k-blocked order
   if (chain_ok(net, rows, 3)) {
@@ -265,6 +269,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
         w->wblk_f[tw][l] = o; o = align64(o + (int64_t)u * ((L.in_dim[l] + 31) & ~31));
         w->wblk_b[tw][l] = o; o = align64(o + (int64_t)((kn + 15) & ~15) * u);
       }
+    for (int tw = 0; tw < 2; ++tw) { w->wblk_h[tw] = o; o = align64(o + 32 * (int64_t)U); }
   }
   w->total = o;
 }
@@ -672,7 +677,8 @@ static void chain_allow_lds() {
     const void* fns[] = {reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(chain_fwd_kernel<CH_PLAIN_ELU>),
                          reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_SILU>),
                          reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
-                         reinterpret_cast<const void*>(wgrad_small_kernel)};
+                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(ppo_chain_kernel<CH_PLAIN_ELU>),
+                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     return true;
   }();
@@ -681,9 +687,10 @@ static void chain_allow_lds() {
 // Weights of towers tw0 .. tw0+towers-1 into the workspace's re-blocked copies: forward order (W of every layer) and / or
 // backward order (W of the layer above, the head for the last layer).  One launch.
 static void launch_reblock(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, int tw0, int towers, bool fwd,
-                           bool bwd, hipStream_t s) {
+                           bool bwd, hipStream_t s, bool heads = false, const RmsMergeArgs* merge = nullptr) {
   ReblockP p;
   memset(&p, 0, sizeof(p));
+  if (merge) { p.merge = *merge; p.has_merge = 1; }
   int piece = 0;
   const int nl = net->n_layers;
   for (int t = 0; t < towers; ++t) {
@@ -706,16 +713,22 @@ static void launch_reblock(const mrl_net* net, const ParamLayout& L, const Works
         piece += ((d.K + 15) & ~15) * u / 4;
       }
     }
+    if (heads) {   // the head as one more forward-order matrix of 32 rows
+      const int U = net->units[nl - 1];
+      ReblockDesc& d = p.d[p.nd++];
+      d.kind = 0; d.src = params + L.Wh[tw]; d.dst = ws + W.wblk_h[tw]; d.N = 32; d.K = U; d.rows = L.head_rows[tw];
+      d.piece0 = piece;
+      piece += 32 * U / 4;
+    }
   }
   p.npieces = piece;
   MRL_PROF_STREAM("mrl::reblock_kernel", s);
-  hipLaunchKernelGGL(reblock_kernel, dim3((unsigned)cdiv(piece, 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(reblock_kernel, dim3((unsigned)cdiv(piece, 256) + (merge ? 1 : 0)), dim3(256), 0, s, p);
 }
 
-static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t rows,
-                             const float* obs_mean, const float* obs_std, float lo, float hi, int tw0, int towers, hipStream_t s, bool blocked_ready) {
-  if (!blocked_ready) launch_reblock(net, L, W, ws, params, tw0, towers, true, false, s);
-  ChainFwdP p;
+static void fill_chain_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t rows,
+                           const float* obs_mean, const float* obs_std, float lo, float hi, int tw0, int towers, ChainFwdP* out) {
+  ChainFwdP& p = *out;
   memset(&p, 0, sizeof(p));
   p.x = x; p.mean = obs_mean; p.stdv = obs_std; p.lo = lo; p.hi = hi;
   p.M = (int)rows; p.in_dim = L.in_dim[0]; p.n_layers = net->n_layers;
@@ -737,6 +750,13 @@ static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Wor
     }
   }
   p.xnorm = (stores_act && obs_mean) ? ws + W.xnorm : nullptr;
+}
+
+static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t rows,
+                             const float* obs_mean, const float* obs_std, float lo, float hi, int tw0, int towers, hipStream_t s, bool blocked_ready) {
+  if (!blocked_ready) launch_reblock(net, L, W, ws, params, tw0, towers, true, false, s);
+  ChainFwdP p;
+  fill_chain_fwd(net, L, W, ws, params, x, rows, obs_mean, obs_std, lo, hi, tw0, towers, &p);
   chain_allow_lds();
   MRL_PROF_STREAM("mrl::chain_fwd_kernel", s);
   const dim3 grid((unsigned)(p.rows_written / CH_ROWS), towers);
@@ -1193,23 +1213,9 @@ __global__ __launch_bounds__(256) void moments_final_kernel(const double* __rest
 __global__ void rms_merge_kernel(double* mean, double* var, double* count, const float* __restrict__ bmean,
                                  const float* __restrict__ bvar, double bcount, int n, float eps, float* mean_f,
                                  float* std_f) {
-  // normalizers.py:44-55, one thread per feature; the count is shared so it is read before anyone writes it
-  int i = threadIdx.x + blockIdx.x * blockDim.x;
-  double cnt = count[0];
-  __syncthreads();
-  if (i < n) {
-    double m = mean[i], v = var[i];
-    double delta = (double)bmean[i] - m;
-    double tot = cnt + bcount;
-    double nm = m + delta * bcount / tot;
-    double m2 = v * cnt + (double)bvar[i] * bcount + delta * delta * cnt * bcount / tot;
-    double nv = m2 / tot;
-    mean[i] = nm;
-    var[i] = nv;
-    if (mean_f) mean_f[i] = (float)nm;
-    if (std_f) std_f[i] = sqrtf((float)nv + eps);
-  }
-  if (i == 0) count[0] = cnt + bcount;
+  RmsMergeArgs a;
+  a.mean = mean; a.var = var; a.count = count; a.bmean = bmean; a.bvar = bvar; a.bcount = bcount; a.n = n; a.eps = eps; a.mean_f = mean_f; a.std_f = std_f;
+  rms_merge_body(a);
 }
 
 __global__ void rms_normalize_kernel(const double* __restrict__ mean, const double* __restrict__ var, float eps, float lo,
@@ -1370,18 +1376,25 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab
   }
 }
 
-__global__ __launch_bounds__(192) void metrics_final_kernel(const double* __restrict__ part, int nblocks, double mb,
-                                                            float critic_coef, float entropy_coef, float bounds_coef,
-                                                            double* __restrict__ out) {
-  // part [nblocks][2][NMETRIC]; 16 threads per metric, fixed-order sums so results are reproducible
-  __shared__ double red[16][MRL_NMETRIC];
-  __shared__ double s[MRL_NMETRIC];
+struct MetricsArgs {
+  const double* part;   // [nblocks][2][MRL_NMETRIC] partial sums of the heads' row blocks
+  int nblocks;
+  double mb;
+  float critic_coef, entropy_coef, bounds_coef;
+  double* out;          // [MRL_NMETRIC]
+};
+
+// the first 192 threads of a block: 16 threads per metric, fixed-order sums so results are reproducible
+__device__ __forceinline__ void metrics_final_body(const double* __restrict__ part, int nblocks, double mb, float critic_coef, float entropy_coef,
+                                                   float bounds_coef, double* __restrict__ out, double (*red)[MRL_NMETRIC], double* s) {
   const int m = threadIdx.x % MRL_NMETRIC, j = threadIdx.x / MRL_NMETRIC;
-  double a = 0;
+  if (j < 16) {
+    double a = 0;
 #pragma unroll 8   // the loads of eight blocks in flight at once; the adds keep their order
-  for (int b = j; b < nblocks; b += 16)
-    a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + m] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + m];
-  red[j][m] = a;
+    for (int b = j; b < nblocks; b += 16)
+      a += part[((int64_t)b * 2 + 0) * MRL_NMETRIC + m] + part[((int64_t)b * 2 + 1) * MRL_NMETRIC + m];
+    red[j][m] = a;
+  }
   __syncthreads();
   if (threadIdx.x < MRL_NMETRIC) {
     double t = 0;
@@ -1401,21 +1414,108 @@ __global__ __launch_bounds__(192) void metrics_final_kernel(const double* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ g, int64_t n, float scale,
-                                                               double* __restrict__ part) {
-  __shared__ double red[256];
-  double s = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float v = g[i] * scale;
-    s += (double)v * v;
-  }
-  red[threadIdx.x] = s;
+__global__ __launch_bounds__(192) void metrics_final_kernel(const double* __restrict__ part, int nblocks, double mb,
+                                                            float critic_coef, float entropy_coef, float bounds_coef,
+                                                            double* __restrict__ out) {
+  __shared__ double red[16][MRL_NMETRIC];
+  __shared__ double s[MRL_NMETRIC];
+  metrics_final_body(part, nblocks, mb, critic_coef, entropy_coef, bounds_coef, out, red, s);
+}
+
+// ---- the squared-norm partials of a flat gradient vector --------------------------------------------------------------
+// The vector is cut into 16-byte chunks; partial b covers chunks [b * 256 * cpt, (b + 1) * 256 * cpt), thread t of its block the
+// chunks (b * cpt + i) * 256 + t, i = 0 .. cpt-1, in that order; the 256 thread sums are combined by a halving tree.  Every
+// kernel that produces these partials (here from the finished vector, reduce_flat_kernel while it writes the vector) follows this
+// one order, so the clip coefficient does not depend on which of them ran.  cpt is chosen so that there are at most 512 partials.
+static inline int norm_cpt(int64_t count) { return (int)std::max<int64_t>(1, cdiv(cdiv(count, 4), 256 * 512)); }
+static inline int norm_parts(int64_t count) { return (int)cdiv(cdiv(count, 4), 256 * (int64_t)norm_cpt(count)); }
+
+__device__ __forceinline__ double norm_tree(double sq, double* red) {
+  red[threadIdx.x] = sq;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+  return red[0];
+}
+__device__ __forceinline__ double norm_chunk(double sq, f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sq += (double)v[e] * (double)v[e];
+  return sq;
+}
+
+// Sum the partial slabs into the flat gradient, one thread per 16-byte chunk of the vector (the descriptors, sorted by their
+// place in the vector, are searched per chunk; chunks that belong to no tensor become zero), slabs added in index order.  The
+// blocks are those of the norm partials above and write them; one more block finishes the metrics of the step.
+struct FlatDesc { const float* src; int64_t stride; int nslabs; int c0, c1; };   // destination chunks [c0, c1)
+struct FlatTable { FlatDesc d[MRL_MAX_RDESC]; int n, cpt, nchunks; };
+
+__global__ __launch_bounds__(256) void reduce_flat_kernel(const FlatTable tab, float* __restrict__ grads, double* __restrict__ norm_part,
+                                                          const MetricsArgs ma) {
+  __shared__ double red[256];
+  if (ma.part && blockIdx.x == gridDim.x - 1) {   // the extra block of launches that finish the metrics
+    double (*mred)[MRL_NMETRIC] = reinterpret_cast<double (*)[MRL_NMETRIC]>(red);
+    __shared__ double ms[MRL_NMETRIC];
+    metrics_final_body(ma.part, ma.nblocks, ma.mb, ma.critic_coef, ma.entropy_coef, ma.bounds_coef, ma.out, mred, ms);
+    return;
+  }
+  __shared__ int s_c0[MRL_MAX_RDESC];
+  __shared__ FlatDesc s_d[MRL_MAX_RDESC];
+  if ((int)threadIdx.x < tab.n) {
+    s_d[threadIdx.x] = tab.d[threadIdx.x];
+    s_c0[threadIdx.x] = tab.d[threadIdx.x].c0;
+  }
+  __syncthreads();
+  double sq = 0.0;
+  for (int i = 0; i < tab.cpt; ++i) {
+    const int c = (blockIdx.x * tab.cpt + i) * 256 + threadIdx.x;
+    if (c >= tab.nchunks) break;
+    int lo = 0, hi = tab.n - 1;   // the last descriptor that starts at or before c
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_c0[mid] <= c) lo = mid; else hi = mid - 1;
+    }
+    const FlatDesc d = s_d[lo];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c >= d.c0 && c < d.c1) {
+      const float* src = d.src + 4 * (int64_t)(c - d.c0);
+      const int ns = d.nslabs;
+      int k = 0;
+      for (; k + 8 <= ns; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + u) * d.stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; k < ns; ++k) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)k * d.stride);
+    }
+    *reinterpret_cast<f32x4*>(grads + 4 * (int64_t)c) = acc;
+    sq = norm_chunk(sq, acc);
+  }
+  const double t = norm_tree(sq, red);
+  if (threadIdx.x == 0) norm_part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float* __restrict__ g, int64_t n, int cpt, float scale,
+                                                               double* __restrict__ part) {
+  __shared__ double red[256];
+  const int64_t nchunks = (n + 3) >> 2;
+  double sq = 0.0;
+  for (int i = 0; i < cpt; ++i) {
+    const int64_t c = ((int64_t)blockIdx.x * cpt + i) * 256 + threadIdx.x;
+    if (c >= nchunks) break;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (4 * c + 3 < n) v = *reinterpret_cast<const f32x4*>(g + 4 * c);
+    else
+      for (int e = 0; 4 * c + e < n; ++e) v[e] = g[4 * c + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mul_rn(v[e], scale);
+    sq = norm_chunk(sq, v);
+  }
+  const double t = norm_tree(sq, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
 struct AdamArgs {
@@ -1430,11 +1530,11 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, const double* __restrict__ norm_part,
                                                    const AdamArgs a, float* __restrict__ gnorm_out) {
-  // every block re-reduces the (<= 256) norm partials in the same fixed order: one partial per thread, then a tree
+  // every block re-reduces the (<= 512) norm partials in the same fixed order: two partials per thread, then a tree
   // through LDS (a single thread walking the list costs a dependent global load per partial)
   __shared__ double s_red[256];
   __shared__ float s_coef;
-  s_red[threadIdx.x] = ((int)threadIdx.x < a.nparts) ? norm_part[threadIdx.x] : 0.0;
+  s_red[threadIdx.x] = (((int)threadIdx.x < a.nparts) ? norm_part[threadIdx.x] : 0.0) + (((int)threadIdx.x + 256 < a.nparts) ? norm_part[threadIdx.x + 256] : 0.0);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
@@ -1791,31 +1891,40 @@ static void launch_input_grad(const mrl_net* net, const ParamLayout& L, const Wo
   launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, dim3(slab_grid(p.n_groups, p.n_tiles), 1, towers), s);
 }
 
+static void fill_chain_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, int64_t mb, int tw0, int towers,
+                           ChainBwdP* out) {
+  ChainBwdP& p = *out;
+  memset(&p, 0, sizeof(p));
+  const int nl = net->n_layers;
+  p.M = (int)mb; p.n_layers = nl; p.ld = chain_ld(net, 32);
+  for (int l = 0; l < nl; ++l) {
+    p.units[l] = net->units[l];
+    for (int t = 0; t < towers; ++t) {
+      const int tw = tw0 + t;
+      p.Wn[t][l] = ws + W.wblk_b[tw][l];
+      p.xhat[t][l] = ws + W.xhat[tw][l];
+      p.rstd[t][l] = ws + W.rstd[tw][l];
+      p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
+      p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
+      p.dz[t][l] = ws + W.dz[tw][l];
+      p.dy[t][l] = L.has_norm ? ws + W.dy[tw][l] : nullptr;
+    }
+  }
+  for (int t = 0; t < towers; ++t) p.seeds[t] = ws + W.seeds[tw0 + t];
+}
+
+static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
+                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, hipStream_t s);
+
 // Backward of a small batch (chain.hip.h): the dgrad chain of all layers in one launch, then (wgrad) every weight gradient of
-// the towers in one launch.  Same buffers as the per-layer launches: dZ per layer, column partials per 16-row block, slabs.
+// the towers in one launch.  Same buffers as the per-layer launches: dZ per layer, column partials per row range, slabs.
 static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
                              const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad, hipStream_t s,
                              bool blocked_ready) {
-  const int nl = net->n_layers, last = nl - 1, U = net->units[last];
   if (!blocked_ready) launch_reblock(net, L, W, ws, params, tw0, towers, false, true, s);
   {
     ChainBwdP p;
-    memset(&p, 0, sizeof(p));
-    p.M = (int)mb; p.n_layers = nl; p.ld = chain_ld(net, 32);
-    for (int l = 0; l < nl; ++l) {
-      p.units[l] = net->units[l];
-      for (int t = 0; t < towers; ++t) {
-        const int tw = tw0 + t;
-        p.Wn[t][l] = ws + W.wblk_b[tw][l];
-        p.xhat[t][l] = ws + W.xhat[tw][l];
-        p.rstd[t][l] = ws + W.rstd[tw][l];
-        p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
-        p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
-        p.dz[t][l] = ws + W.dz[tw][l];
-        p.dy[t][l] = L.has_norm ? ws + W.dy[tw][l] : nullptr;
-      }
-    }
-    for (int t = 0; t < towers; ++t) p.seeds[t] = ws + W.seeds[tw0 + t];
+    fill_chain_bwd(net, L, W, ws, params, mb, tw0, towers, &p);
     chain_allow_lds();
     MRL_PROF_STREAM("mrl::chain_bwd_kernel", s);
     const dim3 grid((unsigned)cdiv(mb, CH_ROWS), towers);
@@ -1824,7 +1933,13 @@ static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Wor
     else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
     else hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
   }
-  if (!wgrad) return;
+  if (wgrad) launch_chain_wgrad(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw0, towers, s);
+}
+
+// Every weight gradient of the towers (layers and heads) in one launch, from the dZ / dY / activations the chain kernels stored.
+static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
+                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, hipStream_t s) {
+  const int nl = net->n_layers, last = nl - 1, U = net->units[last];
   WgradSmallP q;
   memset(&q, 0, sizeof(q));
   q.M = (int)mb; q.nsplit = W.wph.nsplit; q.ksplit = W.wph.ksplit; q.lo = clamp_lo; q.hi = clamp_hi;
@@ -2036,8 +2151,10 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
 
 // Fixed-order reduction of the partial slabs, column partials and head-bias partials of towers tw0 .. tw0+towers-1
 // into the flat gradient vector (layout L).  hblocks = 128-row blocks that produced head-bias partials.
+// whole: the call covers every tensor of the layout, i.e. the whole vector `grads` (then small slab counts take the one-pass kernel
+// that also leaves the squared-norm partials of the vector in the workspace, and finishes the step's metrics when `ma` is given).
 static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, float* grads, int tw0, int towers, int hblocks,
-                               hipStream_t s) {
+                               hipStream_t s, bool whole = false, const MetricsArgs* ma = nullptr, bool* flat_done = nullptr) {
   const int nl = net->n_layers, U = net->units[nl - 1];
   // Every float of the flat gradient is written below: tensor sizes are multiples of 4 floats except the head biases, whose
   // descriptors are rounded up to whole 4-float chunks (zero columns of the partials), and the layout pads offsets to 4.
@@ -2065,6 +2182,34 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
     add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
     // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
     add(ws + W.headb_part + tw * 32, L.bh[tw], align4(L.head_bias_n[tw]), 64, hblocks);
+  }
+  int max_slabs = 0;
+  bool aligned = (L.total & 3) == 0;
+  for (int i = 0; i < tab.n; ++i) {
+    max_slabs = std::max(max_slabs, tab.d[i].nslabs);
+    aligned = aligned && ((tab.d[i].dst - grads) & 3) == 0 && (tab.d[i].count & 3) == 0 && (tab.d[i].stride & 3) == 0;
+  }
+  if (flat_done) *flat_done = false;
+  if (whole && aligned && max_slabs <= 32) {
+    FlatTable ft;
+    ft.n = tab.n;
+    std::sort(tab.d, tab.d + tab.n, [](const ReduceDesc& a, const ReduceDesc& b) { return a.dst < b.dst; });
+    for (int i = 0; i < tab.n; ++i) {
+      const ReduceDesc& d = tab.d[i];
+      ft.d[i].src = d.src; ft.d[i].stride = d.stride; ft.d[i].nslabs = d.nslabs;
+      ft.d[i].c0 = (int)((d.dst - grads) >> 2);
+      ft.d[i].c1 = ft.d[i].c0 + (int)(d.count >> 2);
+    }
+    ft.cpt = norm_cpt(L.total);
+    ft.nchunks = (int)(L.total >> 2);
+    MetricsArgs m;
+    memset(&m, 0, sizeof(m));
+    if (ma) m = *ma;
+    const int nb = norm_parts(L.total);
+    MRL_PROF_STREAM("reduce_flat_kernel", s);
+    hipLaunchKernelGGL(reduce_flat_kernel, dim3(nb + (ma ? 1 : 0)), dim3(256), 0, s, ft, grads, (double*)(ws + W.norm_part), m);
+    if (flat_done) *flat_done = true;
+    return;
   }
   int gx = (int)cdiv(maxcount, 64);
   if (gx > 2048) gx = 2048;
@@ -2118,10 +2263,13 @@ static bool tower_streams(int64_t mb) {
   return forced > 0 && mb > MRL_SMALL_M;
 }
 
-extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
-                            int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
-                            float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
-                            void* stream) {
+// norm_ready (optional): set to true when the squared-norm partials of `grads` were left in the workspace (Workspace::norm_part).
+// merge (optional): the running-statistics merge of the step, folded into the first launch.
+static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
+                         int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
+                         float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
+                         void* stream, bool* norm_ready, const RmsMergeArgs* merge) {
+  if (norm_ready) *norm_ready = false;
   if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
   if (!params || !hp || !grads || !metrics_out || !workspace) MRL_FAIL(MRL_EINVAL, "NULL pointer");
   const int64_t B = buf->num_envs * (int64_t)buf->horizon;
@@ -2140,7 +2288,29 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   const float* x = buf->obs + row0 * O;
 
   double* metric_part = (double*)(ws + W.metric_part);
-  const int hblocks = (int)cdiv(mb, 128);
+  // small batches: the weights re-blocked for the chain kernels, once per call for the forward and the backward pass; with both
+  // chains on (MRL_CHAIN bit 4: in one launch with the heads between them)
+  const bool ch_f = chain_ok(net, mb, 1), ch_b = chain_ok(net, mb, 2), fused = ch_f && ch_b && (chain_mask() & 4) != 0;
+  const int hblocks = (int)cdiv(mb, fused ? CH_ROWS : 128);   // row blocks of the kernel that evaluates the heads
+  auto fill_heads = [&](HeadsP& h) {
+    h.seeds[0] = ws + W.seeds[0];
+    h.seeds[1] = ws + W.seeds[1];
+    if (net->fixed_sigma) h.fixed_logstd = params + L.bh[0] + A;
+    fill_heads_common(net, &h);
+    h.actions = buf->actions + row0 * A;
+    h.mu = buf->mu + row0 * A;
+    h.sigma = buf->sigma + row0 * A;
+    h.old_neglogp = buf->neglogp + row0;
+    h.adv = buf->advantages + row0;
+    h.returns = buf->returns + row0;
+    h.value_preds = buf->values + row0;
+    h.metric_part = metric_part;
+    h.headb_part = ws + W.headb_part;
+    h.inv_mb = 1.0f / (float)mb;
+    h.e_clip = hp->e_clip; h.critic_coef = hp->critic_coef; h.entropy_coef = hp->entropy_coef;
+    h.bounds_coef = hp->bounds_loss_coef; h.bounds_type = hp->bounds_type; h.clip_value_loss = hp->clip_value_loss;
+    h.smooth_clamp = hp->use_smooth_clamp != 0;
+  };
   // heads of towers [tw0, tw0 + towers): losses, KL, seeds d loss / d head, mu / sigma write-back, head-bias partials
   auto launch_heads = [&](int tw0, int towers, hipStream_t st) {
     GemmP p;
@@ -2156,25 +2326,9 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
       p.Kt[k] = U;
     }
     p.tw0 = tw0;
-    p.h.seeds[0] = ws + W.seeds[0];
-    p.h.seeds[1] = ws + W.seeds[1];
-    if (net->fixed_sigma) p.h.fixed_logstd = params + L.bh[0] + A;
     p.lda = U; p.ldb = U;
     p.M = (int)mb; p.N = 32; p.K = U;
-    fill_heads_common(net, &p.h);
-    p.h.actions = buf->actions + row0 * A;
-    p.h.mu = buf->mu + row0 * A;
-    p.h.sigma = buf->sigma + row0 * A;
-    p.h.old_neglogp = buf->neglogp + row0;
-    p.h.adv = buf->advantages + row0;
-    p.h.returns = buf->returns + row0;
-    p.h.value_preds = buf->values + row0;
-    p.h.metric_part = metric_part;
-    p.h.headb_part = ws + W.headb_part;
-    p.h.inv_mb = 1.0f / (float)mb;
-    p.h.e_clip = hp->e_clip; p.h.critic_coef = hp->critic_coef; p.h.entropy_coef = hp->entropy_coef;
-    p.h.bounds_coef = hp->bounds_loss_coef; p.h.bounds_type = hp->bounds_type; p.h.clip_value_loss = hp->clip_value_loss;
-    p.h.smooth_clamp = hp->use_smooth_clamp != 0;
+    fill_heads(p.h);
     if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_ELU>(p, dim3(hblocks, 1, towers), st);
     else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNELU>(p, dim3(hblocks, 1, towers), st);
     else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, towers), st);
@@ -2194,10 +2348,40 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
   const bool planes = L.has_norm && mb > MRL_SMALL_M;
   const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
-  // small batches: the weights re-blocked for the chain kernels, once per call for the forward and the backward pass
-  const bool ch_f = chain_ok(net, mb, 1), ch_b = chain_ok(net, mb, 2);
-  if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s);
-  if (tower_streams(mb)) {
+  if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s, fused, merge);
+  else if (merge)
+    hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1024), 0, s, merge->mean, merge->var, merge->count, merge->bmean, merge->bvar, merge->bcount,
+                       merge->n, merge->eps, merge->mean_f, merge->std_f);
+  if (fused) {
+    // forward, heads and backward of both towers in one launch; every weight gradient in a second one
+    ChainPpoP p;
+    fill_chain_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, &p.f);
+    fill_chain_bwd(net, L, W, ws, params, mb, 0, 2, &p.b);
+    p.b.ld = p.f.ld;
+    memset(&p.h, 0, sizeof(p.h));
+    fill_heads(p.h);
+    for (int tw = 0; tw < 2; ++tw) {
+      p.Wh[tw] = ws + W.wblk_h[tw];
+      p.bh[tw] = params + L.bh[tw];
+      p.head_n[tw] = L.head_rows[tw];
+    }
+    chain_allow_lds();
+    {
+      MRL_PROF_STREAM("mrl::ppo_chain_kernel", s);
+      const dim3 grid((unsigned)(p.f.rows_written / CH_ROWS), 2);
+      const size_t lds = chain_lds_bytes(p.f.ld) + CH_HEADS_F * sizeof(float);
+      if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+      else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+      else hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+    }
+    launch_chain_wgrad(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s);
+    MetricsArgs ma;
+    ma.part = metric_part; ma.nblocks = hblocks; ma.mb = (double)mb;
+    ma.critic_coef = hp->critic_coef; ma.entropy_coef = hp->entropy_coef; ma.bounds_coef = hp->bounds_loss_coef;
+    ma.out = metrics_out;
+    launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s, true, &ma, &metrics_done);
+    if (norm_ready) *norm_ready = metrics_done;
+  } else if (tower_streams(mb)) {
     SideStream* ss = nullptr;
     if (int rc = side_stream(&ss)) return rc;
     if (hipEventRecord(ss->fork, s) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "fork of the tower streams failed");
@@ -2218,16 +2402,26 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
     launch_heads(0, 2, s);
     launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes || ch_b, nullptr, nullptr, &metrics_hook,
                       &metrics_done);
-    launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s);
+    launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s, true, nullptr, norm_ready);
   }
   if (!metrics_done) launch_metrics(s);
   MRL_CHECK_LAUNCH("mrl_ppo_grad");
   return MRL_OK;
 }
 
-extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
-                             double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
-                             float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream) {
+extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
+                            int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
+                            float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+  return ppo_grad_impl(net, params, hp, buf, row0, mb, obs_mean, obs_std, clamp_lo, clamp_hi, grads, metrics_out, workspace, workspace_bytes, stream,
+                       nullptr, nullptr);
+}
+
+// prenorm: the squared-norm partials of `grads` (norm_parts(count) doubles in the order of gradnorm_partial_kernel) when some
+// earlier launch has already produced them, else null
+static int adam_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
+                     float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream, const double* prenorm) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch) MRL_FAIL(MRL_EINVAL, "NULL pointer");
   if (count < 1 || step < 1) MRL_FAIL(MRL_EINVAL, "count %lld / step %lld must be >= 1", (long long)count, (long long)step);
   hipStream_t s = (hipStream_t)stream;
@@ -2247,17 +2441,54 @@ extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, 
   a.adamw = adamw;
   a.nparts = 0;
   MRL_PROF_STREAM("gradnorm_partial_kernel + adam_kernel", s);
+  const double* norm_part = (const double*)scratch;
   if (max_norm > 0.f) {
-    int64_t np = cdiv(count, 2048);
-    a.nparts = (int)(np > 256 ? 256 : np);
-    hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(a.nparts), dim3(256), 0, s, grads, count, grad_scale, (double*)scratch);
+    a.nparts = norm_parts(count);
+    if (prenorm && grad_scale == 1.0f) norm_part = prenorm;
+    else hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(a.nparts), dim3(256), 0, s, grads, count, norm_cpt(count), grad_scale, (double*)scratch);
   }
   int64_t blocks = cdiv(count, 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count,
-                     (const double*)scratch, a, gnorm_out);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count, norm_part, a, gnorm_out);
   MRL_CHECK_LAUNCH("mrl_adam_step");
   return MRL_OK;
+}
+
+extern "C" int mrl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
+                             float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream) {
+  return adam_impl(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, weight_decay, adamw, step, max_norm, grad_scale, gnorm_out, scratch,
+                   stream, nullptr);
+}
+
+extern "C" int mrl_ppo_step(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t row0, int64_t mb,
+                            const mrl_rms* obs_rms, const float* batch_mean, const float* batch_var, double batch_count, float* obs_mean_f32,
+                            float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                            int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, int32_t adamw, int64_t step, float max_norm, float* gnorm_out, void* scratch, void* stream) {
+  RmsMergeArgs m;
+  memset(&m, 0, sizeof(m));
+  if (obs_rms) {
+    if (!obs_rms->mean || !obs_rms->var || !obs_rms->count || !batch_mean || !batch_var || !obs_mean_f32 || !obs_std_f32) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+    if (check_net(net)) return MRL_EINVAL;
+    if (obs_rms->size != net->obs_dim) MRL_FAIL(MRL_EINVAL, "rms size %d != obs_dim %d", obs_rms->size, net->obs_dim);
+    m.mean = obs_rms->mean; m.var = obs_rms->var; m.count = obs_rms->count; m.bmean = batch_mean; m.bvar = batch_var; m.bcount = batch_count;
+    m.n = obs_rms->size; m.eps = obs_rms->eps; m.mean_f = obs_mean_f32; m.std_f = obs_std_f32;
+  }
+  bool norm_ready = false;
+  if (int rc = ppo_grad_impl(net, params, hp, buf, row0, mb, obs_mean_f32, obs_std_f32, clamp_lo, clamp_hi, grads, metrics_out, workspace,
+                             workspace_bytes, stream, &norm_ready, obs_rms ? &m : nullptr))
+    return rc;
+  const double* prenorm = nullptr;
+  if (norm_ready) {
+    Workspace W;
+    workspace_layout(net, mb, &W);
+    prenorm = (const double*)((const float*)workspace + W.norm_part);
+  }
+  ParamLayout L;
+  param_layout(net, &L);
+  return adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, step, max_norm, 1.0f, gnorm_out, scratch,
+                   stream, prenorm);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -96,8 +96,15 @@ def timing(mb=2048, N=2048, Tn=32, steps=300):
     scratch = torch.empty(4096, dtype=torch.uint8, device=DEV)
     n_mb = N * Tn // mb
 
+    one_call = os.environ.get('MRL_ONE_CALL', '1') != '0'
+
     def run(n, adam=True):
         for i in range(n):
+            if adam and one_call:
+                hip.check(L.mrl_ppo_step(model.net, hip.ptr(model.flat), chp, buf.c, (i % n_mb) * mb, mb, None, None, None, 0.0, hip.ptr(mean_f),
+                                         hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads), hip.ptr(metrics), hip.ptr(ws), ws.numel(), hip.ptr(m1), hip.ptr(m2),
+                                         1e-5, 0.9, 0.999, 1e-5, 0.01, 1, i + 1, 0.5, hip.ptr(gn), hip.ptr(scratch), None), 'step')
+                continue
             hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, (i % n_mb) * mb, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0,
                                      hip.ptr(grads), hip.ptr(metrics), hip.ptr(ws), ws.numel(), None), 'grad')
             if adam:
@@ -110,7 +117,7 @@ def timing(mb=2048, N=2048, Tn=32, steps=300):
         run(steps, adam)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f'MRL_CHAIN={os.environ.get("MRL_CHAIN", "default")} mb={mb}: {1e6 * dt / steps:.1f} us per step ({"grad + Adam" if adam else "grad only"})', flush=True)
+        print(f'MRL_CHAIN={os.environ.get("MRL_CHAIN", "default")} mb={mb}: {1e6 * dt / steps:.1f} us per step ({("one call" if one_call else "grad + Adam") if adam else "grad only"})', flush=True)
 
 
 if __name__ == '__main__':
