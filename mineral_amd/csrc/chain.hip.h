@@ -613,14 +613,15 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_bwd_kernel(const ChainBwd
 struct ChainPpoP {
   ChainFwdP f;
   ChainBwdP b;
-  HeadsP h;                    // metric_part [blocks][2][MRL_NMETRIC] and headb_part [blocks][2][32] are per 16-row block here
+  HeadsP h;                    // metric_part [blocks][2][MRL_NMETRIC] is per 16-row block here; headb_part is not written (the weight-gradient
+                               // launch sums the seed columns)
   const float* Wh[2];          // head weights re-blocked in forward order as a [32][U] matrix (rows past the head's outputs zero)
   const float* bh[2];
   int head_n[2];               // head outputs per tower (2 A or A for the actor, 1 for the critic)
 };
 
 constexpr int CH_TS = 33;                                                       // row stride of the head-output tile
-constexpr int CH_HEADS_F = CH_ROWS * CH_TS + 16 * MRL_NMETRIC * 2 + 16 * 32;    // floats of LDS behind the two activation tiles
+constexpr int CH_HEADS_F = CH_ROWS * CH_TS + 16 * MRL_NMETRIC * 2;    // floats of LDS behind the two activation tiles
 
 // head pre-activations of the block's rows: T[row][col] = h[row] . Wh[col] + bias[col], 32 columns (zero weights past the head)
 __device__ __forceinline__ void chain_heads_gemm(const float* WhB, const float* bias, int Nv, int K, const float* hin, int ld, float* T) {
@@ -659,9 +660,8 @@ __device__ __forceinline__ void chain_heads_gemm(const float* WhB, const float* 
 
 // Losses, metrics and seeds of the block's 16 rows from the head outputs T.  Actor blocks: wave w < 4 takes rows 4 w .. 4 w + 3,
 // one per 16-lane group, lane j of the group action j.  Critic blocks: lane l < 16 of wave 0 takes row l.  The seed rows go to the
-// LDS tile `seedt` (the input of the backward chain; rows past the batch zero) and to memory (the heads' weight gradient).
-__device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int m0, int M, const float* T, float* seedt, int ld, double* red2,
-                                                  float* csum) {
+// LDS tile `seedt` (the input of the backward chain; rows past the batch zero) and to memory (the heads' weight and bias gradients).
+__device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int m0, int M, const float* T, float* seedt, int ld, double* red2) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -760,10 +760,6 @@ __device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int 
       for (int c = 2 * A + j; c < 32; c += 16) sd[c] = 0.f;
     }
     const int part = wave * 4 + g;
-    if (jv) {
-      csum[part * 32 + j] = s_mu;
-      csum[part * 32 + A + j] = s_ls;
-    }
     if (j == 0 && rv) {
       double* m = red2 + part * MRL_NMETRIC;
       m[0] = (double)al; m[1] = (double)ent; m[2] = (double)bl; m[3] = (double)kl;
@@ -802,17 +798,14 @@ __device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int 
     }
     const double dr = mine ? (double)ret - (double)v : 0.0;
     double q[5] = {mine ? (double)cl : 0.0, dr, dr * dr, mine ? (double)ret : 0.0, mine ? (double)ret * ret : 0.0};
-    float cs = s_v;
 #pragma unroll
     for (int msk = 1; msk < 16; msk <<= 1) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) q[i] += __shfl_xor(q[i], msk);
-      cs += __shfl_xor(cs, msk);
     }
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) red2[5 + i] = q[i];
-      csum[0] = cs;
     }
   }
 }
@@ -825,26 +818,20 @@ __global__ __launch_bounds__(64 * CH_WAVES) void ppo_chain_kernel(const ChainPpo
   float* nxt = cur + CH_ROWS * p.f.ld;
   float* T = nxt + CH_ROWS * p.f.ld;
   double* red2 = reinterpret_cast<double*>(T + CH_ROWS * CH_TS);   // [16 (wave, group) partials][MRL_NMETRIC]
-  float* csum = reinterpret_cast<float*>(red2 + 16 * MRL_NMETRIC);  // [16][32] seed columns (head-bias gradients)
   const int tid = threadIdx.x, tw = blockIdx.y, m0 = blockIdx.x * CH_ROWS, ld = p.f.ld;
   chain_fwd_body<KIND>(p.f, red, cur, nxt, tw, m0);
   if (m0 >= p.f.M) return;   // blocks of padding rows (the activation tensors are kept finite up to a whole 128-row tile): forward only
   float wpre0[32];
   chain_bwd_prefetch(p.b, tw, p.b.n_layers - 1, 32, wpre0);
   for (int i = tid; i < 16 * MRL_NMETRIC; i += 64 * CH_WAVES) red2[i] = 0.0;
-  csum[tid] = 0.f;
   chain_heads_gemm(p.Wh[tw], p.bh[tw], p.head_n[tw], p.f.units[p.f.n_layers - 1], cur, ld, T);
   __syncthreads();   // T is complete, and every wave has finished copying the last layer's tiles to memory
-  chain_heads_train(p.h, tw, m0, p.f.M, T, nxt, ld, red2, csum);
+  chain_heads_train(p.h, tw, m0, p.f.M, T, nxt, ld, red2);
   __syncthreads();
   if (tid < MRL_NMETRIC) {
     double s = 0.0;
     for (int w = 0; w < 16; ++w) s += red2[w * MRL_NMETRIC + tid];
     p.h.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
-  } else if (tid >= 64 && tid < 96) {
-    float s = 0.f;
-    for (int w = 0; w < 16; ++w) s += csum[w * 32 + tid - 64];
-    p.h.headb_part[((int64_t)blockIdx.x * 2 + tw) * 32 + tid - 64] = s;
   }
   chain_bwd_body<KIND>(p.b, red, nxt, cur, tw, m0, wpre0);
 }

@@ -207,6 +207,8 @@ struct Workspace {
   int64_t xnorm;                   // small batches: the normalised input rows
   int64_t seeds[2];
   int64_t colpart[2][MRL_MAX_LAYERS];
+  int64_t colpart_h[2];  // small batches: [row ranges][3][32] column sums of the head seeds (head-bias gradients) from the weight-gradient launch
+  bool chain_bwd;        // the backward pass of this row count runs the chain kernels and the one-launch weight gradient
   int64_t slab[2][MRL_MAX_LAYERS], slab_h[2];
   int64_t metric_part;   // doubles, 8-byte aligned
   int64_t headb_part;    // [row blocks][2][32] column sums of the head seeds (bias gradients); row blocks of 128 rows, or of 16 (chain kernels)
@@ -229,6 +231,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   // activation tensors are padded to whole 128-row tiles: the LayerNorm epilogues read and write full tiles
   const int64_t rows_pad = cdiv(rows, 128) * 128;
   const bool chain_bwd = chain_ok(net, rows, 2);
+  w->chain_bwd = chain_bwd;
   const bool chain_fb = chain_bwd && chain_ok(net, rows, 1);   // the forward chain stores what the weight gradients read
   int ch_nsplit = 1, ch_ksplit = 64;
   if (chain_bwd) chain_wgrad_split(net, L.in_dim, rows, &ch_nsplit, &ch_ksplit);
@@ -252,6 +255,8 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
     w->wph = wgrad_plan(32, U, rows);
     if (chain_bwd) { w->wph.nsplit = ch_nsplit; w->wph.ksplit = ch_ksplit; }
     w->slab_h[tw] = o; o = align64(o + (int64_t)w->wph.nsplit * 32 * U);
+    w->colpart_h[tw] = o;
+    if (chain_bwd) o = align64(o + (int64_t)ch_nsplit * 3 * 32);
   }
   w->xnorm = o;
   if (chain_fb) o = align64(o + rows_pad * net->obs_dim);
@@ -1966,6 +1971,8 @@ static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const W
         d.colpart = ws + W.colpart[tw][l];
         d.dy = L.has_norm ? ws + W.dy[tw][l] : nullptr;
         d.xout = L.has_norm ? ws + W.xhat[tw][l] : nullptr;
+      } else {       // the head's bias gradient: the column sums of the seeds
+        d.colpart = ws + W.colpart_h[tw];
       }
       d.tiles_n = (int)cdiv(d.in, 64);
       d.tiles = (int)cdiv(d.u, 64) * d.tiles_n;
@@ -2181,7 +2188,8 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
     const int hn = L.head_rows[tw];
     add(ws + W.slab_h[tw], L.Wh[tw], (int64_t)hn * U, (int64_t)32 * U, W.wph.nsplit);
     // counts are rounded up to whole 4-float chunks (the extra columns are zero and land in the layout's padding)
-    add(ws + W.headb_part + tw * 32, L.bh[tw], align4(L.head_bias_n[tw]), 64, hblocks);
+    if (W.chain_bwd) add(ws + W.colpart_h[tw] + 64, L.bh[tw], align4(L.head_bias_n[tw]), 96, W.wph.nsplit);
+    else add(ws + W.headb_part + tw * 32, L.bh[tw], align4(L.head_bias_n[tw]), 64, hblocks);
   }
   int max_slabs = 0;
   bool aligned = (L.total & 3) == 0;
