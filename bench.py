@@ -290,14 +290,18 @@ def main():
                 agent2.train_epoch()
             step2()
             torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            n2 = max(1, min(2, args.steps))
+            n2 = 5
+            times2 = []
             for _ in range(n2):
+                t2 = time.perf_counter()
                 step2()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t2) / n2
+                torch.cuda.synchronize()
+                times2.append(time.perf_counter() - t2)
+            dt2 = sum(times2) / n2
             out['secondary'] = {'minibatch': 2048, 'optimizer_steps_per_update': 5 * args.num_envs * T_HORIZON // 2048, 'updates_timed': n2,
-                                'ms_per_update': 1e3 * dt2, 'value': args.num_envs * T_HORIZON / dt2, 'unit': 'env-steps/s'}
+                                'ms_per_update': 1e3 * dt2, 'ms_per_update_median': 1e3 * sorted(times2)[n2 // 2],
+                                'ms_per_update_all': [round(1e3 * t, 2) for t in times2],
+                                'value': args.num_envs * T_HORIZON / dt2, 'unit': 'env-steps/s'}
         if not args.no_cpu_baseline and not multi:   # the CPU leg is timed at N=1 only
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -25,10 +25,13 @@
 #ifdef CH_TRACE
 // diagnostic builds only (tools/chain_probe.hip): shader-clock stamps of every wave of block (8, 0) of the chain kernels
 __device__ unsigned long long ch_trace_buf[8][64];
+#ifndef CH_TRACE_WG
+#define CH_TRACE_WG 16   // the traced block of the weight-gradient kernels
+#endif
 #define WG_STAMP(slot)                                                                                         \
   do {                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
-    if (blockIdx.x == 16 && (threadIdx.x & 63) == 0 && (slot) < 64) ch_trace_buf[threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x == CH_TRACE_WG && (threadIdx.x & 63) == 0 && (slot) < 64) ch_trace_buf[threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 #define CH_STAMP(slot)                                                                                         \
@@ -72,6 +75,7 @@ struct ChainFwdP {
   float* rstd[2][CH_MAXL];     // [rows_pad]
   float* hact[2][CH_MAXL];     // [rows_pad][units] the layer's output after the activation (operand of the weight gradients), or null
   float* xnorm;                // [rows_pad][in_dim] the normalised input rows (written by the blocks of the first tower), or null
+  int natural;                 // W points at the row-major parameter tensors themselves, not at re-blocked copies
 };
 
 struct ChainBwdP {
@@ -86,6 +90,8 @@ struct ChainBwdP {
   const float* be[2][CH_MAXL];
   float* dz[2][CH_MAXL];       // [rows_pad][units] d loss / d pre-activation
   float* dy[2][CH_MAXL];       // [rows_pad][units] d loss / d LayerNorm output (its column sums are d beta, with x-hat d gamma); null for plain towers
+  int natural;                 // Wn points at the row-major parameter tensors themselves ([wn_rows][units]), not at re-blocked copies
+  int wn_rows[2][CH_MAXL];     // rows of Wn (the width of the layer above; the head's outputs for the last layer)
 };
 
 // Activations live in LDS as [16 rows][ld] with the 16-byte chunks of a row XOR-ed with the row number: the MFMA operand
@@ -140,16 +146,29 @@ __device__ __forceinline__ void ch_copy_out(int tid, const float* tile, int ld, 
 // a scalar offset per tile and step).  Element j of a load is the operand of MFMA j; its k index is the one of element j of the
 // activation chunk 8 step + 4 h + g read from LDS.  A register group is 8 loads = 32 MFMAs per wave, whatever the layer width.
 // ---------------------------------------------------------------------------------------------------------------------
+// where a lane finds the weights of (tile, step, half): byte offset voff + base + tile * tile_stride + step * step_stride + half * half_off
+struct ChFwdAddr { int voff, base, tile_stride, step_stride, half_off, bytes; };
+__device__ __forceinline__ ChFwdAddr chain_fwd_addr(bool natural, int N, int K, int tile0, int lane) {
+  const int steps = (K + 31) >> 5;
+  ChFwdAddr a;
+  if (natural) {   // W[N][K] row-major: lane (r, g) reads W[16 tile + r][32 step + 16 half + 4 g ..]
+    a.voff = ((lane & 15) * K + 4 * (lane >> 4)) * 4; a.tile_stride = 16 * K * 4; a.step_stride = 128; a.half_off = 64; a.bytes = N * K * 4;
+  } else {
+    a.voff = lane * 16; a.tile_stride = steps * 2048; a.step_stride = 2048; a.half_off = 1024; a.bytes = N * steps * 32 * 4;
+  }
+  a.base = tile0 * a.tile_stride;
+  return a;
+}
 template <int TPW>
-__device__ __forceinline__ void chain_fwd_load_group(rsrc_t rsW, int voff, int tile0, int steps, int gi, f32x4 (&w)[8]) {
+__device__ __forceinline__ void chain_fwd_load_group(rsrc_t rsW, const ChFwdAddr& a, int gi, f32x4 (&w)[8]) {
   constexpr int U = 4 / TPW;
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int soff = ((tile0 + i) * steps + gi * U + u) * 2048;
-      w[(u * TPW + i) * 2] = ch_load16(rsW, voff, soff);
-      w[(u * TPW + i) * 2 + 1] = ch_load16(rsW, voff, soff + 1024);
+      const int soff = a.base + i * a.tile_stride + (gi * U + u) * a.step_stride;
+      w[(u * TPW + i) * 2] = ch_load16(rsW, a.voff, soff);
+      w[(u * TPW + i) * 2 + 1] = ch_load16(rsW, a.voff, soff + a.half_off);
     }
 }
 
@@ -159,11 +178,11 @@ __device__ __forceinline__ void chain_fwd_prefetch(const ChainFwdP& p, int tw, i
   const int tpw = ntile >= CH_WAVES ? ntile / CH_WAVES : 1, nact = ntile >= CH_WAVES ? CH_WAVES : ntile;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably wave-uniform: it goes into scalar offsets
   if (wave >= nact) return;
-  const int steps = (K + 31) >> 5;
-  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W[tw][l]), 0, N * steps * 32 * 4, 0x00020000);
-  if (tpw == 4) chain_fwd_load_group<4>(rsW, lane * 16, wave * 4, steps, 0, w0);
-  else if (tpw == 2) chain_fwd_load_group<2>(rsW, lane * 16, wave * 2, steps, 0, w0);
-  else chain_fwd_load_group<1>(rsW, lane * 16, wave, steps, 0, w0);
+  const ChFwdAddr a = chain_fwd_addr(p.natural != 0, N, K, wave * tpw, lane);
+  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W[tw][l]), 0, a.bytes, 0x00020000);
+  if (tpw == 4) chain_fwd_load_group<4>(rsW, a, 0, w0);
+  else if (tpw == 2) chain_fwd_load_group<2>(rsW, a, 0, w0);
+  else chain_fwd_load_group<1>(rsW, a, 0, w0);
 }
 
 // One layer of N outputs on the block's 16 rows.  xin [16][ld] (K valid columns, zero up to the next multiple of 32); hout
@@ -203,12 +222,12 @@ __device__ __forceinline__ void chain_fwd_layer(const ChainFwdP& p, int tw, int 
       }
     }
     const int steps = (K + 31) >> 5;
-    const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W[tw][l]), 0, N * steps * 32 * 4, 0x00020000);
-    const int voff = lane * 16, tile0 = wave * TPW;
+    const ChFwdAddr wad = chain_fwd_addr(p.natural != 0, N, K, wave * TPW, lane);
+    const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W[tw][l]), 0, wad.bytes, 0x00020000);
     f32x4 (&wa)[8] = wpre0;   // the group prefetched during the layer before
     f32x4 wb[8];
     const int ngroups = (steps + U - 1) / U;
-    if (ngroups > 1) chain_fwd_load_group<TPW>(rsW, voff, tile0, steps, 1, wb);
+    if (ngroups > 1) chain_fwd_load_group<TPW>(rsW, wad, 1, wb);
     auto compute_group = [&](int gi, const f32x4 (&w)[8]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -230,10 +249,10 @@ __device__ __forceinline__ void chain_fwd_layer(const ChainFwdP& p, int tw, int 
     // two register groups in turn: a group is reloaded (two groups ahead) as soon as its MFMAs have been issued
     for (int gi = 0; gi < ngroups; gi += 2) {
       compute_group(gi, wa);
-      if (gi + 2 < ngroups) chain_fwd_load_group<TPW>(rsW, voff, tile0, steps, gi + 2, wa);
+      if (gi + 2 < ngroups) chain_fwd_load_group<TPW>(rsW, wad, gi + 2, wa);
       if (gi + 1 < ngroups) {
         compute_group(gi + 1, wb);
-        if (gi + 3 < ngroups) chain_fwd_load_group<TPW>(rsW, voff, tile0, steps, gi + 3, wb);
+        if (gi + 3 < ngroups) chain_fwd_load_group<TPW>(rsW, wad, gi + 3, wb);
       }
     }
   }
@@ -390,14 +409,27 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_fwd_kernel(const ChainFwd
 // feature 16 J wave + J i + jj.  A lane (batch row r16, g) then holds 4 J CONSECUTIVE features from 4 J (4 wave + g): e = J r + jj.
 // A register group is 32 floats = 32 MFMAs per wave, whatever the layer width.
 // ---------------------------------------------------------------------------------------------------------------------
+// where a lane finds its J weights of (step, s): byte offset voff + base + step * step_stride + s * s_stride
+struct ChBwdAddr { int voff, base, step_stride, s_stride, bytes; };
+__device__ __forceinline__ ChBwdAddr chain_bwd_addr(bool natural, int J, int N, int K, int rows, int wave, int lane) {
+  const int steps = (K + 15) >> 4;
+  ChBwdAddr a;
+  if (natural) {   // Wn[rows][N] row-major: lane (i, g) reads Wn[16 step + 4 g + s][16 J wave + J i ..]; rows past the matrix read as zeros
+    a.voff = (4 * (lane >> 4) * N + J * (lane & 15)) * 4; a.base = 16 * J * wave * 4; a.step_stride = 16 * N * 4; a.s_stride = N * 4; a.bytes = rows * N * 4;
+  } else {
+    a.voff = lane * J * 4; a.base = wave * steps * 4 * 64 * J * 4; a.step_stride = 4 * 64 * J * 4; a.s_stride = 64 * J * 4; a.bytes = steps * 16 * N * 4;
+  }
+  return a;
+}
 template <int J>
-__device__ __forceinline__ void chain_bwd_load_group(rsrc_t rsW, int voff, int wave, int steps, int gi, float (&w)[32]) {
+__device__ __forceinline__ void chain_bwd_load_group(rsrc_t rsW, const ChBwdAddr& a, int gi, float (&w)[32]) {
   constexpr int U = 8 / J;
+  const int voff = a.voff;
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int soff = ((wave * steps + gi * U + u) * 4 + s) * 64 * J * 4;
+      const int soff = a.base + (gi * U + u) * a.step_stride + s * a.s_stride;
       if constexpr (J == 4) {
         const f32x4 t = ch_load16(rsW, voff, soff);
 #pragma unroll
@@ -423,11 +455,11 @@ __device__ __forceinline__ void chain_bwd_prefetch(const ChainBwdP& p, int tw, i
   const int nact = N / (16 * J) < CH_WAVES ? N / (16 * J) : CH_WAVES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // provably wave-uniform: it goes into scalar offsets
   if (wave >= nact) return;
-  const int steps = (K + 15) >> 4;
-  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wn[tw][l]), 0, steps * 16 * N * 4, 0x00020000);
-  if (J == 4) chain_bwd_load_group<4>(rsW, lane * 16, wave, steps, 0, w0);
-  else if (J == 2) chain_bwd_load_group<2>(rsW, lane * 8, wave, steps, 0, w0);
-  else chain_bwd_load_group<1>(rsW, lane * 4, wave, steps, 0, w0);
+  const ChBwdAddr a = chain_bwd_addr(p.natural != 0, J, N, K, p.wn_rows[tw][l], wave, lane);
+  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wn[tw][l]), 0, a.bytes, 0x00020000);
+  if (J == 4) chain_bwd_load_group<4>(rsW, a, 0, w0);
+  else if (J == 2) chain_bwd_load_group<2>(rsW, a, 0, w0);
+  else chain_bwd_load_group<1>(rsW, a, 0, w0);
 }
 
 template <int N, int KIND>
@@ -467,12 +499,12 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
     }
     if constexpr (HAS_NORM) rstd = p.rstd[tw][l][row];
     const int steps = (K + 15) >> 4;
-    const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wn[tw][l]), 0, steps * 16 * N * 4, 0x00020000);
-    const int voff = lane * J * 4;
+    const ChBwdAddr wad = chain_bwd_addr(p.natural != 0, J, N, K, p.wn_rows[tw][l], wave, lane);
+    const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wn[tw][l]), 0, wad.bytes, 0x00020000);
     float (&wa)[32] = wpre0;   // the group prefetched during the layer before
     float wb[32];
     const int ngroups = (steps + U - 1) / U;
-    if (ngroups > 1) chain_bwd_load_group<J>(rsW, voff, wave, steps, 1, wb);
+    if (ngroups > 1) chain_bwd_load_group<J>(rsW, wad, 1, wb);
     auto compute_group = [&](int gi, const float (&w)[32]) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -488,10 +520,10 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
     };
     for (int gi = 0; gi < ngroups; gi += 2) {
       compute_group(gi, wa);
-      if (gi + 2 < ngroups) chain_bwd_load_group<J>(rsW, voff, wave, steps, gi + 2, wa);
+      if (gi + 2 < ngroups) chain_bwd_load_group<J>(rsW, wad, gi + 2, wa);
       if (gi + 1 < ngroups) {
         compute_group(gi + 1, wb);
-        if (gi + 3 < ngroups) chain_bwd_load_group<J>(rsW, voff, wave, steps, gi + 3, wb);
+        if (gi + 3 < ngroups) chain_bwd_load_group<J>(rsW, wad, gi + 3, wb);
       }
     }
   }
@@ -624,21 +656,22 @@ constexpr int CH_TS = 33;                                                       
 constexpr int CH_HEADS_F = CH_ROWS * CH_TS + 16 * MRL_NMETRIC * 2;    // floats of LDS behind the two activation tiles
 
 // head pre-activations of the block's rows: T[row][col] = h[row] . Wh[col] + bias[col], 32 columns (zero weights past the head)
-__device__ __forceinline__ void chain_heads_gemm(const float* WhB, const float* bias, int Nv, int K, const float* hin, int ld, float* T) {
+__device__ __forceinline__ void chain_heads_gemm(const float* WhB, bool natural, const float* bias, int Nv, int K, const float* hin, int ld, float* T) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
   if (wave >= 2) return;
   const int steps = K >> 5;   // layer widths are multiples of 32
-  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WhB), 0, 32 * steps * 32 * 4, 0x00020000);
+  const ChFwdAddr a = chain_fwd_addr(natural, natural ? Nv : 32, K, wave, lane);   // natural: rows past the head's outputs read as zeros
+  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(WhB), 0, a.bytes, 0x00020000);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < steps; s0 += 4) {
     f32x4 w[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int soff = (wave * steps + min(s0 + u, steps - 1)) * 2048;
-      w[2 * u] = ch_load16(rsW, lane * 16, soff);
-      w[2 * u + 1] = ch_load16(rsW, lane * 16, soff + 1024);
+      const int soff = a.base + min(s0 + u, steps - 1) * a.step_stride;
+      w[2 * u] = ch_load16(rsW, a.voff, soff);
+      w[2 * u + 1] = ch_load16(rsW, a.voff, soff + a.half_off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -824,7 +857,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) void ppo_chain_kernel(const ChainPpo
   float wpre0[32];
   chain_bwd_prefetch(p.b, tw, p.b.n_layers - 1, 32, wpre0);
   for (int i = tid; i < 16 * MRL_NMETRIC; i += 64 * CH_WAVES) red2[i] = 0.0;
-  chain_heads_gemm(p.Wh[tw], p.bh[tw], p.head_n[tw], p.f.units[p.f.n_layers - 1], cur, ld, T);
+  chain_heads_gemm(p.Wh[tw], p.f.natural != 0, p.bh[tw], p.head_n[tw], p.f.units[p.f.n_layers - 1], cur, ld, T);
   __syncthreads();   // T is complete, and every wave has finished copying the last layer's tiles to memory
   chain_heads_train(p.h, tw, m0, p.f.M, T, nxt, ld, red2);
   __syncthreads();
@@ -1100,6 +1133,211 @@ __global__ __launch_bounds__(512) void wgrad_small_kernel(const WgradSmallP p) {
     case PRO_LNELU: wgrad_small_cols<PRO_LNELU>(p, d, split, m0, n0, hf); break;
     default: wgrad_small_cols<PRO_NONE>(p, d, split, m0, n0, hf); break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradients, block tiles: the same slabs as wgrad_small_kernel from a block of 8 waves per 128 x 128 (or 128 x 64)
+// tile of one dW and one range of batch rows.  Both operands are staged through LDS 32 rows at a time (every thread loads 16
+// bytes per operand and 16 rows, coalesced along the feature dimension; the loads of the stage after next fly during the
+// MFMAs of this one), so a CU reads each operand element once per tile instead of once per wave, and the matrix core
+// operands come from LDS: lane (i, g) takes dZ[k0 + g][m0 + MT i .. + MT-1] and X[k0 + g][n0 + 2 i, + 1] per 4-row step and
+// feeds MT x 2 accumulators.  Operands as stored by the forward chain (no prologue).
+// The threads that load dZ also sum what they load: column sums of dZ (d bias), and with dY / x-hat of the layer, of dY
+// (d beta) and dY * x-hat (d gamma), for the tiles of the first column block.
+// Row ranges are whole 32-row stages, dealt out evenly: split s of n takes stages [s G / n, (s + 1) G / n) of the G stages.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WgTileDesc {
+  const float* dz;       // [M][u]
+  const float* xin;      // [M][in]
+  float* slab;           // [nsplit][u][in]
+  const float* dy;       // [M][u] or null
+  const float* xout;     // [M][u] x-hat of this layer (with dy)
+  float* colpart;        // [nsplit][3][u] d gamma, d beta, d bias partial column sums, or null
+  int u, in, bn;         // bn: 128 or 64 columns per tile
+  int tiles_n, tiles, nsplit, task0;
+};
+struct WgTileP { WgTileDesc d[WG_MAXDESC]; int nd, ntasks, M; };
+constexpr int WT_LD = 132;                       // floats per staged row: 128 + 4, so that the four k-groups of a read start on different banks
+constexpr int WT_ROWS = 32;                      // rows per stage
+constexpr int WT_LDS_F = 2 * 2 * WT_ROWS * WT_LD;   // floats: two stages of two operands
+
+template <int BN>
+__device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDesc& d, int split, int m0, int n0, float* lds) {
+  constexpr int WN = BN == 128 ? 4 : 2, WM = 8 / WN;   // waves along the columns / rows of the tile
+  constexpr int MT = 128 / WM / 16;                    // rows per lane and 4-row step: wave tile (16 MT) x 32
+  float* As = lds;
+  float* Bs = lds + 2 * WT_ROWS * WT_LD;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15, kg = lane >> 4;
+  const int wm0 = (wave / WN) * (16 * MT), wn0 = (wave % WN) * 32;
+  const int G = (p.M + WT_ROWS - 1) / WT_ROWS;
+  const int s0 = (int)((int64_t)split * G / d.nsplit), s1 = (int)((int64_t)(split + 1) * G / d.nsplit);
+  const int nst = s1 - s0, k0 = s0 * WT_ROWS;
+  const int cols = (n0 == 0 && d.colpart) ? (d.dy ? 2 : 1) : 0;
+  // loader role of this thread: rows lr and lr + 16 of a stage, 4 columns from col4
+  const int lr = tid >> 5, col4 = (tid & 31) * 4;
+  const bool loadsB = col4 < BN;
+  // rows past the batch read as zeros (descriptor bounds); columns past a matrix's width wrap into the next row and only feed
+  // outputs that are not stored
+  const rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dz), 0, p.M * d.u * 4, 0x00020000);
+  const rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.xin), 0, p.M * d.in * 4, 0x00020000);
+  const rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy ? d.dy : d.dz), 0, p.M * d.u * 4, 0x00020000);
+  const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy ? d.xout : d.dz), 0, p.M * d.u * 4, 0x00020000);
+  const int voffZ = (lr * d.u + m0 + col4) * 4, voffX = (lr * d.in + n0 + col4) * 4;
+  const int h16Z = 16 * d.u * 4, h16X = 16 * d.in * 4;     // bytes per 16 rows
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) acc[j][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cz = {0.f, 0.f, 0.f, 0.f}, cg = cz, cb = cz;
+  // two register sets: the loads of a stage are issued two stages before its rows go to LDS
+  struct Regs { f32x4 a[2], b[2], y[2], o[2]; };
+  Regs r0, r1;
+  auto load_stage = [&](int s, Regs& r) {
+    const int sz = (k0 + s * WT_ROWS) * d.u * 4, sx = (k0 + s * WT_ROWS) * d.in * 4;
+    r.a[0] = ch_load16(rsZ, voffZ, sz);
+    r.a[1] = ch_load16(rsZ, voffZ, sz + h16Z);
+    if (loadsB) {
+      r.b[0] = ch_load16(rsX, voffX, sx);
+      r.b[1] = ch_load16(rsX, voffX, sx + h16X);
+    }
+    if (cols == 2) {
+      r.y[0] = ch_load16(rsY, voffZ, sz);
+      r.y[1] = ch_load16(rsY, voffZ, sz + h16Z);
+      r.o[0] = ch_load16(rsO, voffZ, sz);
+      r.o[1] = ch_load16(rsO, voffZ, sz + h16Z);
+    }
+  };
+  auto store_stage = [&](int buf, const Regs& r) {
+    float* a = As + buf * WT_ROWS * WT_LD + lr * WT_LD + col4;
+    *reinterpret_cast<f32x4*>(a) = r.a[0];
+    *reinterpret_cast<f32x4*>(a + 16 * WT_LD) = r.a[1];
+    if (loadsB) {
+      float* b = Bs + buf * WT_ROWS * WT_LD + lr * WT_LD + col4;
+      *reinterpret_cast<f32x4*>(b) = r.b[0];
+      *reinterpret_cast<f32x4*>(b + 16 * WT_LD) = r.b[1];
+    }
+    if (cols >= 1) cz += r.a[0] + r.a[1];
+    if (cols == 2) {
+      cg += r.y[0] * r.o[0] + r.y[1] * r.o[1];
+      cb += r.y[0] + r.y[1];
+    }
+  };
+  auto compute_stage = [&](int buf) {
+    const float* a = As + buf * WT_ROWS * WT_LD + kg * WT_LD + wm0 + MT * i16;
+    const float* b = Bs + buf * WT_ROWS * WT_LD + kg * WT_LD + wn0 + 2 * i16;
+#pragma unroll
+    for (int ks = 0; ks < WT_ROWS / 4; ++ks) {
+      float av[MT];
+      if constexpr (MT == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + ks * 4 * WT_LD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = v[j];
+      } else {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(a + ks * 4 * WT_LD);
+        av[0] = v[0]; av[1] = v[1];
+      }
+      const f32x2 bv = *reinterpret_cast<const f32x2*>(b + ks * 4 * WT_LD);
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) acc[j][t2] = ch_mfma(av[j], bv[t2], acc[j][t2]);
+    }
+  };
+  WG_STAMP(0);
+  if (nst > 0) {
+    load_stage(0, r0);
+    if (nst > 1) load_stage(1, r1);
+    store_stage(0, r0);
+    if (nst > 2) load_stage(2, r0);
+    __syncthreads();
+    WG_STAMP(1);
+    // stage s is multiplied from buffer s & 1 while stage s + 1 goes from registers into the other buffer (every wave left that
+    // one at the barrier that ended stage s - 1) and the loads of stage s + 3 are issued; the late waves of a stage go from their
+    // last MFMA straight to the barrier
+    // The two waves of a SIMD take the register-to-LDS step at different ends of the stage (waves 0-3 before their MFMAs,
+    // waves 4-7 after), so that one of them always has MFMAs to issue.
+    const bool early = wave < 4;
+    for (int s = 0; s < nst; s += 2) {
+      auto refill1 = [&] {
+        if (s + 1 < nst) {
+          store_stage(1, r1);
+          if (s + 3 < nst) load_stage(s + 3, r1);
+        }
+      };
+      auto refill0 = [&] {
+        if (s + 2 < nst) {
+          store_stage(0, r0);
+          if (s + 4 < nst) load_stage(s + 4, r0);
+        }
+      };
+      if (early) refill1();
+      compute_stage(0);
+      if (!early) refill1();
+      WG_STAMP(2 + 2 * s);
+      __syncthreads();
+      WG_STAMP(3 + 2 * s);
+      if (s + 1 < nst) {
+        if (early) refill0();
+        compute_stage(1);
+        if (!early) refill0();
+        WG_STAMP(4 + 2 * s);
+        __syncthreads();
+        WG_STAMP(5 + 2 * s);
+      }
+    }
+  }
+  // lane (c = i16, kg) holds rows m0 + wm0 + MT (4 kg + r) + j, columns n0 + wn0 + 2 c + (0, 1) in acc[j][0..1][r]
+  float* out = d.slab + (int64_t)split * d.u * d.in;
+  const int col = n0 + wn0 + 2 * i16;
+  if (col < d.in) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = m0 + wm0 + MT * (4 * kg + r) + j;
+        if (orow < d.u) *reinterpret_cast<f32x2*>(out + (int64_t)orow * d.in + col) = f32x2{acc[j][0][r], acc[j][1][r]};
+      }
+  }
+  WG_STAMP(40);
+  if (cols >= 1) {
+    // column sums: the 16 loader rows of a column chunk are combined in a fixed order through LDS (all waves are past the last barrier)
+    f32x4* red = reinterpret_cast<f32x4*>(lds);            // [3][16][32 chunks]
+    red[(0 * 16 + lr) * 32 + (tid & 31)] = cz;
+    if (cols == 2) {
+      red[(1 * 16 + lr) * 32 + (tid & 31)] = cg;
+      red[(2 * 16 + lr) * 32 + (tid & 31)] = cb;
+    }
+    __syncthreads();
+    const int q = tid >> 5, ch = tid & 31;                 // quantity 0 d bias, 1 d gamma, 2 d beta
+    if (q < (cols == 2 ? 3 : 1) && m0 + 4 * ch < d.u) {
+      f32x4 s = red[(q * 16) * 32 + ch];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) s += red[(q * 16 + r) * 32 + ch];
+      float* cp = d.colpart + (int64_t)split * 3 * d.u;
+      const int slot = q == 0 ? 2 : (q == 1 ? 0 : 1);      // colpart order: d gamma, d beta, d bias
+      *reinterpret_cast<f32x4*>(cp + slot * d.u + m0 + 4 * ch) = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileP p) {
+  extern __shared__ __attribute__((aligned(16))) float wt_lds[];
+  // blocks are handed to the 8 XCDs in turn: remapped so that every XCD works on one contiguous eighth of the task list (the
+  // tiles of one row range read the same rows)
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int task = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  int di = 0;
+  for (int q = 1; q < p.nd; ++q)
+    if (task >= p.d[q].task0) di = q;
+  const WgTileDesc& d = p.d[di];
+  const int local = task - d.task0;
+  const int split = local / d.tiles, tile = local - split * d.tiles;
+  const int m0 = (tile / d.tiles_n) * 128, n0 = (tile % d.tiles_n) * d.bn;
+  if (d.bn == 128) wgrad_tile_task<128>(p, d, split, m0, n0, wt_lds);
+  else wgrad_tile_task<64>(p, d, split, m0, n0, wt_lds);
 }
 
 }  // namespace mrl

@@ -161,6 +161,8 @@ static int chain_mask() {
   static const int m = [] { const char* e = getenv("MRL_CHAIN"); return e ? atoi(e) : 7; }();
   return m;
 }
+// MRL_CHAIN bit 8: the chain kernels read the weights from the parameter tensors as they are (no re-blocked copies, no launch that makes them)
+static bool chain_natural() { return (chain_mask() & 8) != 0; }
 static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
   return (chain_mask() & bit) != 0 && rows <= MRL_SMALL_M && net->n_layers <= CH_MAXL;
 }
@@ -180,6 +182,32 @@ static void chain_wgrad_split(const mrl_net* net, const int* in_dim, int64_t row
   if (ks < 64) ks = 64;
   *ksplit = (int)ks;
   *nsplit = (int)cdiv(rows, ks);
+}
+
+// Block-tile weight gradients (wgrad_tile_kernel; MRL_CHAIN bit 16 keeps the wave-tile kernel): column blocks of 64 for inputs of at
+// most 64 columns, else 128; row ranges per gradient so that the launch has at most one block per CU (MRL_CHAIN_TASKS, default 256)
+// and every block about the same number of MFMAs: gradients with 64-column tiles get half as many ranges.  Index n_layers = the heads.
+struct ChainWgPlan { int bn[MRL_MAX_LAYERS + 1], nsplit[MRL_MAX_LAYERS + 1]; };
+static bool chain_tile_wgrad(const mrl_net* net, int64_t rows) { return chain_ok(net, rows, 3) && (chain_mask() & 16) == 0; }
+static ChainWgPlan chain_wgrad_plan(const mrl_net* net, const int* in_dim, int64_t rows) {
+  static const int target = [] { const char* e = getenv("MRL_CHAIN_TASKS"); return e ? atoi(e) : 256; }();
+  ChainWgPlan pl;
+  const int nl = net->n_layers;
+  int tiles[MRL_MAX_LAYERS + 1];
+  for (int l = 0; l <= nl; ++l) {
+    const int u = l == nl ? 32 : net->units[l], in = l == nl ? net->units[nl - 1] : in_dim[l];
+    pl.bn[l] = in <= 64 ? 64 : 128;
+    tiles[l] = (int)(cdiv(u, 128) * cdiv(in, pl.bn[l]));
+  }
+  const int maxs = (int)std::max<int64_t>(1, cdiv(rows, 32) / 2);   // at least 64 rows per range
+  int best = 1;
+  for (int sp = 1; sp <= maxs; ++sp) {
+    int total = 0;
+    for (int l = 0; l <= nl; ++l) total += 2 * tiles[l] * (pl.bn[l] == 128 ? sp : (sp + 1) / 2);
+    if (total <= target) best = sp;
+  }
+  for (int l = 0; l <= nl; ++l) pl.nsplit[l] = pl.bn[l] == 128 ? best : (best + 1) / 2;
+  return pl;
 }
 
 static WgradPlan wgrad_plan(int gm, int gn, int64_t rows) {
@@ -235,6 +263,9 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   const bool chain_fb = chain_bwd && chain_ok(net, rows, 1);   // the forward chain stores what the weight gradients read
   int ch_nsplit = 1, ch_ksplit = 64;
   if (chain_bwd) chain_wgrad_split(net, L.in_dim, rows, &ch_nsplit, &ch_ksplit);
+  const bool tile_wg = chain_tile_wgrad(net, rows);
+  ChainWgPlan tp;
+  if (tile_wg) tp = chain_wgrad_plan(net, L.in_dim, rows);
   for (int tw = 0; tw < 2; ++tw) {
     for (int l = 0; l < net->n_layers; ++l) {
       int u = net->units[l];
@@ -243,20 +274,20 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
       if (chain_bwd) { w->dy[tw][l] = o; o = align64(o + rows_pad * u); }
       if (chain_fb) { w->hact[tw][l] = o; o = align64(o + rows_pad * u); }
-      if (chain_bwd) w->rowblocks[l] = ch_nsplit;                                             // column partials per row range of the weight-gradient launch
+      if (chain_bwd) w->rowblocks[l] = tile_wg ? tp.nsplit[l] : ch_nsplit;                    // column partials per row range of the weight-gradient launch
       else if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
       else w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
-      if (chain_bwd) { w->wp[l].nsplit = ch_nsplit; w->wp[l].ksplit = ch_ksplit; }
+      if (chain_bwd) { w->wp[l].nsplit = tile_wg ? tp.nsplit[l] : ch_nsplit; w->wp[l].ksplit = ch_ksplit; }
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
     }
     w->seeds[tw] = o; o = align64(o + rows * 32);
     w->wph = wgrad_plan(32, U, rows);
-    if (chain_bwd) { w->wph.nsplit = ch_nsplit; w->wph.ksplit = ch_ksplit; }
+    if (chain_bwd) { w->wph.nsplit = tile_wg ? tp.nsplit[net->n_layers] : ch_nsplit; w->wph.ksplit = ch_ksplit; }
     w->slab_h[tw] = o; o = align64(o + (int64_t)w->wph.nsplit * 32 * U);
     w->colpart_h[tw] = o;
-    if (chain_bwd) o = align64(o + (int64_t)ch_nsplit * 3 * 32);
+    if (chain_bwd) o = align64(o + (int64_t)w->wph.nsplit * 3 * 32);
   }
   w->xnorm = o;
   if (chain_fb) o = align64(o + rows_pad * net->obs_dim);
@@ -683,16 +714,24 @@ static void chain_allow_lds() {
                          reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_SILU>),
                          reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
                          reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(ppo_chain_kernel<CH_PLAIN_ELU>),
-                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel)};
+                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     return true;
   }();
   (void)once;
 }
+__global__ void rms_merge_kernel(double* mean, double* var, double* count, const float* __restrict__ bmean, const float* __restrict__ bvar,
+                                 double bcount, int n, float eps, float* mean_f, float* std_f);
 // Weights of towers tw0 .. tw0+towers-1 into the workspace's re-blocked copies: forward order (W of every layer) and / or
 // backward order (W of the layer above, the head for the last layer).  One launch.
 static void launch_reblock(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, int tw0, int towers, bool fwd,
                            bool bwd, hipStream_t s, bool heads = false, const RmsMergeArgs* merge = nullptr) {
+  if (chain_natural()) {
+    if (merge)
+      hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1024), 0, s, merge->mean, merge->var, merge->count, merge->bmean, merge->bvar, merge->bcount,
+                         merge->n, merge->eps, merge->mean_f, merge->std_f);
+    return;
+  }
   ReblockP p;
   memset(&p, 0, sizeof(p));
   if (merge) { p.merge = *merge; p.has_merge = 1; }
@@ -745,7 +784,7 @@ static void fill_chain_fwd(const mrl_net* net, const ParamLayout& L, const Works
     p.units[l] = net->units[l];
     for (int t = 0; t < towers; ++t) {
       const int tw = tw0 + t;
-      p.W[t][l] = ws + W.wblk_f[tw][l];
+      p.W[t][l] = chain_natural() ? params + L.W[tw][l] : ws + W.wblk_f[tw][l];
       p.b[t][l] = params + L.b[tw][l];
       p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
       p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
@@ -755,6 +794,7 @@ static void fill_chain_fwd(const mrl_net* net, const ParamLayout& L, const Works
     }
   }
   p.xnorm = (stores_act && obs_mean) ? ws + W.xnorm : nullptr;
+  p.natural = chain_natural();
 }
 
 static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t rows,
@@ -1530,6 +1570,7 @@ struct AdamArgs {
   float bc2_sqrt, eps, neg_step_size;
   float max_norm, grad_scale;
   int adamw, nparts;
+  int vec4;             // the four vectors are 16-byte aligned
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1554,16 +1595,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   __syncthreads();
   const float coef = s_coef;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = mul_rn(mul_rn(g[i], a.grad_scale), coef);
-    float pi = p[i];
+  auto update = [&](float gi, float& pi, float& mi, float& vi) {
+    gi = mul_rn(mul_rn(gi, a.grad_scale), coef);
     if (a.adamw) pi = mul_rn(pi, a.lr_wd_mul);
     else if (a.l2 != 0.f) gi = add_rn(gi, mul_rn(a.l2, pi));
-    float mi = m[i], vi = v[i];
     mi = add_rn(mi, mul_rn(a.one_m_b1, sub_rn(gi, mi)));                       // exp_avg.lerp_(g, 1-b1)
     vi = add_rn(mul_rn(vi, a.b2), mul_rn(mul_rn(a.one_m_b2, gi), gi));      // mul_(b2).addcmul_(g,g,1-b2)
-    float denom = add_rn(div_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+    const float denom = add_rn(div_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
     pi = add_rn(pi, mul_rn(a.neg_step_size, div_rn(mi, denom)));                // addcdiv_(m, denom, -step)
+  };
+  // 16 bytes per thread and pass when the vectors allow it (all four share the alignment of the pointers checked by the host)
+  const int64_t n4 = a.vec4 ? (n >> 2) : 0;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (int64_t)gridDim.x * 256) {
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * c);
+    f32x4 p4 = *reinterpret_cast<f32x4*>(p + 4 * c), m4 = *reinterpret_cast<f32x4*>(m + 4 * c), v4 = *reinterpret_cast<f32x4*>(v + 4 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pi = p4[e], mi = m4[e], vi = v4[e];
+      update(g4[e], pi, mi, vi);
+      p4[e] = pi; m4[e] = mi; v4[e] = vi;
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * c) = p4;
+    *reinterpret_cast<f32x4*>(m + 4 * c) = m4;
+    *reinterpret_cast<f32x4*>(v + 4 * c) = v4;
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    update(g[i], pi, mi, vi);
     p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
@@ -1906,7 +1964,9 @@ static void fill_chain_bwd(const mrl_net* net, const ParamLayout& L, const Works
     p.units[l] = net->units[l];
     for (int t = 0; t < towers; ++t) {
       const int tw = tw0 + t;
-      p.Wn[t][l] = ws + W.wblk_b[tw][l];
+      const bool lastl = l == nl - 1;
+      p.Wn[t][l] = chain_natural() ? (lastl ? params + L.Wh[tw] : params + L.W[tw][l + 1]) : ws + W.wblk_b[tw][l];
+      p.wn_rows[t][l] = lastl ? L.head_rows[tw] : net->units[l + 1];
       p.xhat[t][l] = ws + W.xhat[tw][l];
       p.rstd[t][l] = ws + W.rstd[tw][l];
       p.g[t][l] = L.has_norm ? params + L.g[tw][l] : nullptr;
@@ -1916,6 +1976,7 @@ static void fill_chain_bwd(const mrl_net* net, const ParamLayout& L, const Works
     }
   }
   for (int t = 0; t < towers; ++t) p.seeds[t] = ws + W.seeds[tw0 + t];
+  p.natural = chain_natural();
 }
 
 static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
@@ -1945,6 +2006,37 @@ static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Wor
 static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params, const float* x, int64_t mb,
                                const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, hipStream_t s) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
+  if (chain_tile_wgrad(net, mb)) {
+    const ChainWgPlan pl = chain_wgrad_plan(net, L.in_dim, mb);
+    WgTileP q;
+    memset(&q, 0, sizeof(q));
+    q.M = (int)mb;
+    int task = 0;
+    for (int t = 0; t < towers; ++t) {
+      const int tw = tw0 + t;
+      for (int l = last + 1; l >= 0; --l) {
+        WgTileDesc& d = q.d[q.nd++];
+        const bool head = l == last + 1;
+        d.u = head ? 32 : net->units[l];
+        d.in = head ? U : L.in_dim[l];
+        d.dz = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
+        d.xin = (l == 0) ? (obs_mean ? ws + W.xnorm : x) : ws + W.hact[tw][l - 1];
+        d.slab = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
+        d.colpart = head ? ws + W.colpart_h[tw] : ws + W.colpart[tw][l];
+        if (!head && L.has_norm) { d.dy = ws + W.dy[tw][l]; d.xout = ws + W.xhat[tw][l]; }
+        d.bn = pl.bn[l];
+        d.nsplit = pl.nsplit[l];
+        d.tiles_n = (int)cdiv(d.in, d.bn);
+        d.tiles = (int)cdiv(d.u, 128) * d.tiles_n;
+        d.task0 = task;
+        task += d.tiles * d.nsplit;
+      }
+    }
+    q.ntasks = task;
+    MRL_PROF_STREAM("mrl::wgrad_tile_kernel", s);
+    hipLaunchKernelGGL(wgrad_tile_kernel, dim3((unsigned)task), dim3(512), WT_LDS_F * sizeof(float), s, q);
+    return;
+  }
   WgradSmallP q;
   memset(&q, 0, sizeof(q));
   q.M = (int)mb; q.nsplit = W.wph.nsplit; q.ksplit = W.wph.ksplit; q.lo = clamp_lo; q.hi = clamp_hi;
@@ -2369,7 +2461,7 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
     memset(&p.h, 0, sizeof(p.h));
     fill_heads(p.h);
     for (int tw = 0; tw < 2; ++tw) {
-      p.Wh[tw] = ws + W.wblk_h[tw];
+      p.Wh[tw] = chain_natural() ? params + L.Wh[tw] : ws + W.wblk_h[tw];
       p.bh[tw] = params + L.bh[tw];
       p.head_n[tw] = L.head_rows[tw];
     }
@@ -2455,7 +2547,9 @@ static int adam_impl(float* params, const float* grads, float* exp_avg, float* e
     if (prenorm && grad_scale == 1.0f) norm_part = prenorm;
     else hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(a.nparts), dim3(256), 0, s, grads, count, norm_cpt(count), grad_scale, (double*)scratch);
   }
-  int64_t blocks = cdiv(count, 256);
+  a.vec4 = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+             reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+  int64_t blocks = cdiv(a.vec4 ? cdiv(count, 4) : count, 256);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count, norm_part, a, gnorm_out);
   MRL_CHECK_LAUNCH("mrl_adam_step");

@@ -111,6 +111,24 @@ int main(int argc, char** argv) {
     }
   }
   rb.npieces = piece; w.ntasks = task;
+  // block-tile weight gradients: 9 row ranges for the 128-column tiles, 5 for the 64-column ones
+  WgTileP wt; memset(&wt, 0, sizeof(wt));
+  wt.M = M;
+  int ttask = 0;
+  const int sfull = argc > 4 ? atoi(argv[4]) : 9;
+  for (int i = 0; i < w.nd; ++i) {
+    const WgDesc& o = w.d[i];
+    WgTileDesc& d = wt.d[wt.nd++];
+    d.dz = o.dz; d.xin = o.xin; d.dy = o.dy; d.xout = o.xout; d.u = o.u; d.in = o.in;
+    d.bn = d.in <= 64 ? 64 : 128;
+    d.nsplit = d.bn == 128 ? sfull : (sfull + 1) / 2;
+    d.slab = dalloc((size_t)d.nsplit * d.u * d.in, 0, 0.f);
+    d.colpart = dalloc((size_t)d.nsplit * 3 * d.u, 0, 0.f);
+    d.tiles_n = (d.in + d.bn - 1) / d.bn; d.tiles = ((d.u + 127) / 128) * d.tiles_n; d.task0 = ttask; ttask += d.tiles * d.nsplit;
+  }
+  wt.ntasks = ttask;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  auto run_wt = [&] { hipLaunchKernelGGL(wgrad_tile_kernel, dim3(ttask), dim3(512), WT_LDS_F * 4, 0, wt); };
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_fwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -164,6 +182,8 @@ int main(int argc, char** argv) {
   time_it("chain_bwd", run_b, false);
   time_it("chain_bwd", run_b, true);
   time_it("wgrad_small", run_w, false);
+  printf("wgrad_tile: %d blocks\n", ttask);
+  time_it("wgrad_tile", run_wt, false);
 #ifdef CH_TRACE
   auto dump_trace = [&](const char* name, auto fn) {
     for (int i = 0; i < 5; ++i) fn();
@@ -188,6 +208,18 @@ int main(int argc, char** argv) {
     for (int wv = 0; wv < 8; ++wv) {
       printf("  wave %d:", wv);
       for (int sl = 1; sl <= 2 * ((w.ksplit + 31) / 32); ++sl) printf(" %6lld", (long long)(h[wv][sl] - h[wv][0]));
+      printf("  | stores %6lld\n", (long long)(h[wv][40] - h[wv][0]));
+    }
+  }
+  {
+    for (int i = 0; i < 5; ++i) run_wt();
+    CK(hipDeviceSynchronize());
+    unsigned long long h[8][64];
+    CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ch_trace_buf), sizeof(h)));
+    printf("wgrad_tile block 16: cycles since task start, per wave: first barrier | [stage computed, stage barrier] ... | slab stores issued\n");
+    for (int wv = 0; wv < 8; ++wv) {
+      printf("  wave %d: %6lld |", wv, (long long)(h[wv][1] - h[wv][0]));
+      for (int sl = 2; sl <= 17; ++sl) printf(" %6lld", (long long)(h[wv][sl] - h[wv][0]));
       printf("  | stores %6lld\n", (long long)(h[wv][40] - h[wv][0]));
     }
   }
