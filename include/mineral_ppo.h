@@ -232,6 +232,21 @@ int mrl_ppo_step(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const 
                  float* exp_avg_sq, double lr, double beta1, double beta2, double eps, double weight_decay,
                  int32_t adamw, int64_t step, float max_norm, float* gnorm_out, void* scratch, void* stream);
 
+/* One mini-epoch of PPO.train_epoch (the inner loop of ppo.py:254-313 over the minibatches of the rollout) for callers
+ * without a gradient all-reduce: minibatch i = rows [i*mb, (i+1)*mb) of the buffer, i = 0 .. n_minibatches-1, in
+ * order; exactly n_minibatches calls of mrl_ppo_step with batch_mean / batch_var = row i of batch_means / batch_vars
+ * ([n_minibatches][obs_dim]), metrics_out + i*MRL_NMETRIC, step = first_step + i, gnorm_out + i (gnorm_out may be
+ * NULL), and bit-identical to them; the learning rate is the same for all steps (the KL-adaptive schedule changes
+ * it between mini-epochs, ppo.py:337-345).  Inside one call the library carries state from step to step (the
+ * optimizer writes the parameters straight into the layouts the next step's kernels read). */
+int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb,
+                       int64_t n_minibatches, const mrl_rms* obs_rms, const float* batch_means,
+                       const float* batch_vars, double batch_count, float* obs_mean_f32, float* obs_std_f32,
+                       float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                       int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int32_t adamw, int64_t first_step,
+                       float max_norm, float* gnorm_out, void* scratch, void* stream);
+
 /* Benchmark support, no counterpart in the reference: time the MFMA GEMM launches with HIP events on the stream
  * they are issued to.  mode 0 = off (default), 1 = every GEMM instantiation, 2 = only the instantiation that has
  * accumulated the most time so far (call after a mode-1 warm-up; with nothing timed since the last call the choice of the last

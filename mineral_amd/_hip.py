@@ -113,6 +113,9 @@ _SIGNATURES = {
     'mrl_ppo_step': (C.c_int, [C.POINTER(Net), _P, C.POINTER(PpoHp), C.POINTER(Rollout), C.c_int64, C.c_int64, C.POINTER(Rms), _P, _P, C.c_double,
                                _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
+    'mrl_ppo_mini_epoch': (C.c_int, [C.POINTER(Net), _P, C.POINTER(PpoHp), C.POINTER(Rollout), C.c_int64, C.c_int64, C.POINTER(Rms), _P, _P,
+                                     C.c_double, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
     'mrl_nstep_emit': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int32, C.POINTER(Transitions), C.c_int64, C.c_int32, _P,
                                  C.POINTER(Transitions), _P]),
     'mrl_replay_write': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int64, C.POINTER(Transitions), C.c_int64, _P]),

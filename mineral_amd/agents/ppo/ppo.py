@@ -316,22 +316,21 @@ class PPO(Agent):
         for mini_ep in range(self.mini_epochs):
             self.mini_epoch += 1
             k0 = k
-            for i in range(n_mb):
-                if self._dist is None:
-                    # no collective between backward and optimizer.step(): the whole step in one call (bit-identical to the three
-                    # calls of the other branch)
-                    self.optim_step += 1
-                    _hip.check(L.mrl_ppo_step(net, _hip.ptr(flat), self.hp, buf.c, i * mb, mb, obs_rms,
-                                              _hip.ptr(self._mb_mean[i]) if obs_rms is not None else None,
-                                              _hip.ptr(self._mb_var[i]) if obs_rms is not None else None, count,
-                                              _hip.ptr(self._obs_mean_f) if obs_rms is not None else None,
-                                              _hip.ptr(self._obs_std_f) if obs_rms is not None else None, lo, hi,
-                                              _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(),
-                                              _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), self._optim_lr, self.betas[0], self.betas[1],
-                                              self.adam_eps, self.weight_decay, adamw, self.optim_step, max_norm,
-                                              _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_ppo_step')
-                    k += 1
-                    continue
+            if self._dist is None:
+                # no collective between backward and optimizer.step(): the whole mini-epoch in one call (bit-identical to the
+                # per-minibatch calls of the other branch)
+                _hip.check(L.mrl_ppo_mini_epoch(net, _hip.ptr(flat), self.hp, buf.c, mb, n_mb, obs_rms,
+                                                _hip.ptr(self._mb_mean) if obs_rms is not None else None,
+                                                _hip.ptr(self._mb_var) if obs_rms is not None else None, count,
+                                                _hip.ptr(self._obs_mean_f) if obs_rms is not None else None,
+                                                _hip.ptr(self._obs_std_f) if obs_rms is not None else None, lo, hi,
+                                                _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(),
+                                                _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), self._optim_lr, self.betas[0], self.betas[1],
+                                                self.adam_eps, self.weight_decay, adamw, self.optim_step + 1, max_norm,
+                                                _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_ppo_mini_epoch')
+                self.optim_step += n_mb
+                k += n_mb
+            for i in range(n_mb if self._dist is not None else 0):
                 if self.normalize_input:
                     _hip.check(L.mrl_rms_merge(obs_rms, _hip.ptr(self._mb_mean[i]), _hip.ptr(self._mb_var[i]), count,
                                                _hip.ptr(self._obs_mean_f), _hip.ptr(self._obs_std_f), s), 'mrl_rms_merge')

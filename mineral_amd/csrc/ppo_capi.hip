@@ -2368,7 +2368,7 @@ static bool tower_streams(int64_t mb) {
 static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf,
                          int64_t row0, int64_t mb, const float* obs_mean, const float* obs_std, float clamp_lo,
                          float clamp_hi, float* grads, double* metrics_out, void* workspace, int64_t workspace_bytes,
-                         void* stream, bool* norm_ready, const RmsMergeArgs* merge) {
+                         void* stream, bool* norm_ready, const RmsMergeArgs* merge, bool blocked_valid = false) {
   if (norm_ready) *norm_ready = false;
   if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
   if (!params || !hp || !grads || !metrics_out || !workspace) MRL_FAIL(MRL_EINVAL, "NULL pointer");
@@ -2448,7 +2448,9 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
   const bool planes = L.has_norm && mb > MRL_SMALL_M;
   const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
-  if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s, fused, merge);
+  if (blocked_valid) {
+    if (!fused || merge) MRL_FAIL(MRL_EINVAL, "internal: re-blocked weights can only be carried between the steps of the one-launch chain");
+  } else if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s, fused, merge);
   else if (merge)
     hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1024), 0, s, merge->mean, merge->var, merge->count, merge->bmean, merge->bvar, merge->bcount,
                        merge->n, merge->eps, merge->mean_f, merge->std_f);
@@ -2517,11 +2519,88 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
                        nullptr, nullptr);
 }
 
+// adam_kernel that also keeps the re-blocked weight copies of the chain kernels current (reblock_kernel's layouts), for callers that
+// run several optimizer steps back to back: chunks of the parameter vector that belong to a weight matrix go to their places in the
+// forward-order and backward-order copies as they are written.  One more block merges the next step's batch moments into the
+// running statistics.  Zero padding of the copies is never touched: a reblock_kernel launch must have written them once.
+struct ArDesc { int c0, c1, K; float* fdst; int fsteps; float* bdst; int bJ, bsteps; };   // chunks [c0, c1) are a row-major [rows][K] matrix
+constexpr int AR_MAXDESC = 2 * (MRL_MAX_LAYERS + 1);
+struct ArTable { ArDesc d[AR_MAXDESC]; int n, has_merge; RmsMergeArgs merge; };
+
+__global__ __launch_bounds__(256) void adam_reblock_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, int64_t n, const double* __restrict__ norm_part,
+                                                           const AdamArgs a, float* __restrict__ gnorm_out, const ArTable tab) {
+  if (tab.has_merge && blockIdx.x == gridDim.x - 1) {
+    rms_merge_body(tab.merge);
+    return;
+  }
+  __shared__ double s_red[256];
+  __shared__ float s_coef;
+  s_red[threadIdx.x] = (((int)threadIdx.x < a.nparts) ? norm_part[threadIdx.x] : 0.0) + (((int)threadIdx.x + 256 < a.nparts) ? norm_part[threadIdx.x + 256] : 0.0);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float norm = (float)sqrt(s_red[0]);
+    float coef = 1.0f;
+    if (a.max_norm > 0.f) coef = fminf(a.max_norm / (norm + 1e-6f), 1.0f);   // torch clip_grad_norm_
+    s_coef = coef;
+    if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = norm;
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const int nblk = gridDim.x - (tab.has_merge ? 1 : 0);
+  const int64_t n4 = n >> 2;   // the host checks n % 4 == 0 and the alignment
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (int64_t)nblk * 256) {
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * c);
+    f32x4 p4 = *reinterpret_cast<f32x4*>(p + 4 * c), m4 = *reinterpret_cast<f32x4*>(m + 4 * c), v4 = *reinterpret_cast<f32x4*>(v + 4 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gi = mul_rn(mul_rn(g4[e], a.grad_scale), coef);
+      float pi = p4[e], mi = m4[e], vi = v4[e];
+      if (a.adamw) pi = mul_rn(pi, a.lr_wd_mul);
+      else if (a.l2 != 0.f) gi = add_rn(gi, mul_rn(a.l2, pi));
+      mi = add_rn(mi, mul_rn(a.one_m_b1, sub_rn(gi, mi)));
+      vi = add_rn(mul_rn(vi, a.b2), mul_rn(mul_rn(a.one_m_b2, gi), gi));
+      const float denom = add_rn(div_rn(sqrtf(vi), a.bc2_sqrt), a.eps);
+      pi = add_rn(pi, mul_rn(a.neg_step_size, div_rn(mi, denom)));
+      p4[e] = pi; m4[e] = mi; v4[e] = vi;
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * c) = p4;
+    *reinterpret_cast<f32x4*>(m + 4 * c) = m4;
+    *reinterpret_cast<f32x4*>(v + 4 * c) = v4;
+    int hit = -1;
+    for (int q = 0; q < tab.n; ++q)
+      if (c >= tab.d[q].c0 && c < tab.d[q].c1) hit = q;
+    if (hit >= 0) {
+      int c0 = 0, K = 4, fsteps = 0, bJ = 1, bsteps = 0;
+      float* fdst = nullptr;
+      float* bdst = nullptr;
+      for (int q = 0; q < tab.n; ++q)   // the descriptors stay in scalar registers; the lane picks its own by comparison
+        if (q == hit) { c0 = tab.d[q].c0; K = tab.d[q].K; fdst = tab.d[q].fdst; fsteps = tab.d[q].fsteps; bdst = tab.d[q].bdst; bJ = tab.d[q].bJ; bsteps = tab.d[q].bsteps; }
+      const int e = 4 * ((int)c - c0);
+      const int row = e / K, k = e - row * K;
+      if (fdst) {
+        const int piece = (((row >> 4) * fsteps + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + ((k >> 2) & 3) * 16 + (row & 15);
+        *reinterpret_cast<f32x4*>(fdst + (int64_t)piece * 4) = p4;
+      }
+      if (bdst) {
+        const int w16 = 16 * bJ, nw = k / w16, rem = k - nw * w16;
+        const int idx = ((((nw * bsteps + (row >> 4)) * 4 + (row & 3)) * 4 + ((row >> 2) & 3)) * 16) * bJ + rem;
+        *reinterpret_cast<f32x4*>(bdst + idx) = p4;
+      }
+    }
+  }
+}
+
 // prenorm: the squared-norm partials of `grads` (norm_parts(count) doubles in the order of gradnorm_partial_kernel) when some
 // earlier launch has already produced them, else null
 static int adam_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int32_t adamw, int64_t step,
-                     float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream, const double* prenorm) {
+                     float max_norm, float grad_scale, float* gnorm_out, void* scratch, void* stream, const double* prenorm,
+                     const ArTable* reblock = nullptr) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch) MRL_FAIL(MRL_EINVAL, "NULL pointer");
   if (count < 1 || step < 1) MRL_FAIL(MRL_EINVAL, "count %lld / step %lld must be >= 1", (long long)count, (long long)step);
   hipStream_t s = (hipStream_t)stream;
@@ -2551,6 +2630,13 @@ static int adam_impl(float* params, const float* grads, float* exp_avg, float* e
              reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
   int64_t blocks = cdiv(a.vec4 ? cdiv(count, 4) : count, 256);
   if (blocks > 1024) blocks = 1024;
+  if (reblock) {
+    if (!a.vec4 || (count & 3)) MRL_FAIL(MRL_EINVAL, "the multi-step update needs 16-byte aligned vectors of a multiple of 4 floats");
+    hipLaunchKernelGGL(adam_reblock_kernel, dim3((unsigned)blocks + (reblock->has_merge ? 1 : 0)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count,
+                       norm_part, a, gnorm_out, *reblock);
+    MRL_CHECK_LAUNCH("mrl_ppo_mini_epoch");
+    return MRL_OK;
+  }
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, count, norm_part, a, gnorm_out);
   MRL_CHECK_LAUNCH("mrl_adam_step");
   return MRL_OK;
@@ -2591,6 +2677,73 @@ extern "C" int mrl_ppo_step(const mrl_net* net, float* params, const mrl_ppo_hp*
   param_layout(net, &L);
   return adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, step, max_norm, 1.0f, gnorm_out, scratch,
                    stream, prenorm);
+}
+
+extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb, int64_t n_minibatches,
+                                  const mrl_rms* obs_rms, const float* batch_means, const float* batch_vars, double batch_count, float* obs_mean_f32,
+                                  float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                                  int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                                  double weight_decay, int32_t adamw, int64_t first_step, float max_norm, float* gnorm_out, void* scratch, void* stream) {
+  if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
+  if (n_minibatches < 1 || mb < 2 || mb * n_minibatches > buf->num_envs * (int64_t)buf->horizon)
+    MRL_FAIL(MRL_EINVAL, "%lld minibatches of %lld rows do not fit the batch", (long long)n_minibatches, (long long)mb);
+  if (!metrics_out) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (obs_rms && (!batch_means || !batch_vars || !obs_mean_f32 || !obs_std_f32 || !obs_rms->mean || !obs_rms->var || !obs_rms->count)) MRL_FAIL(MRL_EINVAL, "NULL pointer");
+  if (obs_rms && obs_rms->size != net->obs_dim) MRL_FAIL(MRL_EINVAL, "rms size %d != obs_dim %d", obs_rms->size, net->obs_dim);
+  const int O = net->obs_dim;
+  ParamLayout L;
+  param_layout(net, &L);
+  Workspace W;
+  workspace_layout(net, mb, &W);
+  auto merge_of = [&](int64_t i) {
+    RmsMergeArgs m;
+    memset(&m, 0, sizeof(m));
+    m.mean = obs_rms->mean; m.var = obs_rms->var; m.count = obs_rms->count; m.bmean = batch_means + i * O; m.bvar = batch_vars + i * O; m.bcount = batch_count;
+    m.n = obs_rms->size; m.eps = obs_rms->eps; m.mean_f = obs_mean_f32; m.std_f = obs_std_f32;
+    return m;
+  };
+  // With the one-launch chain the optimizer keeps the re-blocked weight copies current from the second step on (and merges the next
+  // step's moments); otherwise this is a plain loop over mrl_ppo_step.
+  const bool carry = chain_ok(net, mb, 3) && (chain_mask() & 4) != 0 && !chain_natural() && (L.total & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+                       reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+  ArTable tab;
+  memset(&tab, 0, sizeof(tab));
+  if (carry) {
+    float* ws = (float*)workspace;
+    const int nl = net->n_layers, U = net->units[nl - 1];
+    auto jof = [](int n) { return n >= 512 ? 4 : (n >= 256 ? 2 : 1); };
+    for (int tw = 0; tw < 2; ++tw) {
+      for (int l = 0; l < nl; ++l) {
+        ArDesc& d = tab.d[tab.n++];
+        const int u = net->units[l], K = L.in_dim[l];
+        d.c0 = (int)(L.W[tw][l] >> 2); d.c1 = d.c0 + u * K / 4; d.K = K;
+        d.fdst = ws + W.wblk_f[tw][l]; d.fsteps = (K + 31) >> 5;
+        if (l > 0) { d.bdst = ws + W.wblk_b[tw][l - 1]; d.bJ = jof(K); d.bsteps = (u + 15) >> 4; }
+      }
+      ArDesc& d = tab.d[tab.n++];
+      d.c0 = (int)(L.Wh[tw] >> 2); d.c1 = d.c0 + L.head_rows[tw] * U / 4; d.K = U;
+      d.fdst = ws + W.wblk_h[tw]; d.fsteps = U >> 5;
+      d.bdst = ws + W.wblk_b[tw][nl - 1]; d.bJ = jof(U); d.bsteps = 2;
+    }
+  }
+  for (int64_t i = 0; i < n_minibatches; ++i) {
+    RmsMergeArgs m0;
+    const bool first = i == 0 || !carry;
+    if (obs_rms && first) m0 = merge_of(i);
+    bool norm_ready = false;
+    if (int rc = ppo_grad_impl(net, params, hp, buf, i * mb, mb, obs_mean_f32, obs_std_f32, clamp_lo, clamp_hi, grads, metrics_out + i * MRL_NMETRIC,
+                               workspace, workspace_bytes, stream, &norm_ready, (obs_rms && first) ? &m0 : nullptr, !first))
+      return rc;
+    const double* prenorm = norm_ready ? (const double*)((const float*)workspace + W.norm_part) : nullptr;
+    const bool more = carry && i + 1 < n_minibatches;
+    tab.has_merge = (more && obs_rms) ? 1 : 0;
+    if (tab.has_merge) tab.merge = merge_of(i + 1);
+    if (int rc = adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, first_step + i, max_norm, 1.0f,
+                           gnorm_out ? gnorm_out + i : nullptr, scratch, stream, prenorm, more ? &tab : nullptr))
+      return rc;
+  }
+  return MRL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -911,41 +911,47 @@ def test_an_optimizer_step_replays_from_a_hip_graph(hip, mb):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('mb,net', [(256, 'full'), (2048, 'full'), (296, 'cartpole'), (16384, 'full')])
-def test_the_one_call_optimizer_step_equals_the_three_calls(hip, mb, net):
+def test_the_one_call_step_and_mini_epoch_equal_the_three_calls(hip, mb, net):
     """mrl_ppo_step folds the launches of mrl_rms_merge -> mrl_ppo_grad -> mrl_adam_step into each other (statistics merge in the
-    first launch, gradient norm taken while the gradient is written); parameters, Adam moments, running statistics, metrics,
-    gradient and gradient norm after three steps must equal the three calls' bit for bit."""
+    first launch, gradient norm taken while the gradient is written), and mrl_ppo_mini_epoch runs the steps of consecutive
+    minibatches in one call (the optimizer writes the weights straight into the layouts the next step reads).  Parameters, Adam
+    moments, running statistics, metrics, gradient and gradient norm after three steps on three minibatches must equal the
+    three calls' bit for bit."""
     from mineral_amd.common.normalizers import RunningMeanStd
     spec = NETS[net]
-    T = 8
-    N = mb // T
+    T, steps = 8, 3
+    N = steps * mb // T
     params = oracle_params(spec, 9)
     L = hip.lib()
     chp = hip.PpoHp(0.2, 4.0, 0.01, 1e-4, 0, 0, 0)
     outs = []
-    for one_call in (False, True):
+    for mode in ('three calls', 'one call per step', 'one call'):
         model = make_model(spec, params)
         buf = make_buffer(spec, N, T, mb)
         _fill_training_buffer(spec, buf, N, T)
         P = model.param_count
         ws = torch.zeros(int(L.mrl_workspace_bytes(model.net, mb)), dtype=torch.uint8, device=DEV)
         grads, m, v = (torch.zeros(P, device=DEV) for _ in range(3))
-        metrics = torch.zeros(3, hip.NMETRIC, dtype=torch.float64, device=DEV)
-        gnorm = torch.zeros(3, device=DEV)
+        metrics = torch.zeros(steps, hip.NMETRIC, dtype=torch.float64, device=DEV)
+        gnorm = torch.zeros(steps, device=DEV)
         scratch = torch.empty(4096, dtype=torch.uint8, device=DEV)
         rms = RunningMeanStd((spec['obs'],), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
-        obs2d = buf.storage_dict['obses']['obs'].reshape(N * T, -1)
-        bmean, bvar = obs2d.mean(0).contiguous(), obs2d.var(0, correction=1).contiguous()
+        obs3d = buf.storage_dict['obses']['obs'].reshape(steps, mb, -1)
+        bmean, bvar = obs3d.mean(1).contiguous(), obs3d.var(1, correction=1).contiguous()
         mean_f, std_f = torch.empty(spec['obs'], device=DEV), torch.empty(spec['obs'], device=DEV)
         c = rms.c_struct()
-        for k in range(3):
-            if one_call:
-                hip.check(L.mrl_ppo_step(model.net, hip.ptr(model.flat), chp, buf.c, 0, mb, c, hip.ptr(bmean), hip.ptr(bvar), float(mb), hip.ptr(mean_f),
-                                         hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads), hip.ptr(metrics[k]), hip.ptr(ws), ws.numel(), hip.ptr(m), hip.ptr(v),
-                                         5e-4, 0.9, 0.999, 1e-5, 0.01, 1, k + 1, 0.5, hip.ptr(gnorm[k:]), hip.ptr(scratch), None), 'step')
+        if mode == 'one call':
+            hip.check(L.mrl_ppo_mini_epoch(model.net, hip.ptr(model.flat), chp, buf.c, mb, steps, c, hip.ptr(bmean), hip.ptr(bvar), float(mb), hip.ptr(mean_f),
+                                           hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads), hip.ptr(metrics), hip.ptr(ws), ws.numel(), hip.ptr(m), hip.ptr(v),
+                                           5e-4, 0.9, 0.999, 1e-5, 0.01, 1, 1, 0.5, hip.ptr(gnorm), hip.ptr(scratch), None), 'mini-epoch')
+        for k in range(steps if mode != 'one call' else 0):
+            if mode == 'one call per step':
+                hip.check(L.mrl_ppo_step(model.net, hip.ptr(model.flat), chp, buf.c, k * mb, mb, c, hip.ptr(bmean[k]), hip.ptr(bvar[k]), float(mb),
+                                         hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads), hip.ptr(metrics[k]), hip.ptr(ws), ws.numel(), hip.ptr(m),
+                                         hip.ptr(v), 5e-4, 0.9, 0.999, 1e-5, 0.01, 1, k + 1, 0.5, hip.ptr(gnorm[k:]), hip.ptr(scratch), None), 'step')
             else:
-                hip.check(L.mrl_rms_merge(c, hip.ptr(bmean), hip.ptr(bvar), float(mb), hip.ptr(mean_f), hip.ptr(std_f), None), 'merge')
-                hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, 0, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads),
+                hip.check(L.mrl_rms_merge(c, hip.ptr(bmean[k]), hip.ptr(bvar[k]), float(mb), hip.ptr(mean_f), hip.ptr(std_f), None), 'merge')
+                hip.check(L.mrl_ppo_grad(model.net, hip.ptr(model.flat), chp, buf.c, k * mb, mb, hip.ptr(mean_f), hip.ptr(std_f), -5.0, 5.0, hip.ptr(grads),
                                          hip.ptr(metrics[k]), hip.ptr(ws), ws.numel(), None), 'grad')
                 hip.check(L.mrl_adam_step(hip.ptr(model.flat), hip.ptr(grads), hip.ptr(m), hip.ptr(v), P, 5e-4, 0.9, 0.999, 1e-5, 0.01, 1, k + 1, 0.5, 1.0,
                                           hip.ptr(gnorm[k:]), hip.ptr(scratch), None), 'adam')
@@ -954,8 +960,9 @@ def test_the_one_call_optimizer_step_equals_the_three_calls(hip, mb, net):
                                          buf.storage_dict['mu'], buf.storage_dict['sigma'])])
     assert all(bool(torch.isfinite(t).all()) for t in outs[0])
     assert float(outs[0][5].min()) > 0.0
-    for i, (a, b) in enumerate(zip(*outs)):
-        assert torch.equal(a, b), f'tensor {i} differs between the three calls and the one call'
+    for o, mode in zip(outs[1:], ('one call per step', 'one call')):
+        for i, (a, b) in enumerate(zip(outs[0], o)):
+            assert torch.equal(a, b), f'tensor {i} differs between the three calls and {mode}'
 
 
 @pytest.mark.gpu
