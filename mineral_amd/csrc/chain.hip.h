@@ -25,6 +25,8 @@
 #ifdef CH_TRACE
 // diagnostic builds only (tools/chain_probe.hip): shader-clock stamps of every wave of block (8, 0) of the chain kernels
 __device__ unsigned long long ch_trace_buf[8][64];
+__device__ unsigned long long ch_block_clk[1024][2];   // 100 MHz clock at entry / exit of every block of the traced weight-gradient launch
+#define WG_BLOCK(which) do { if (threadIdx.x == 0 && blockIdx.x < 1024) ch_block_clk[blockIdx.x][which] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #ifndef CH_TRACE_WG
 #define CH_TRACE_WG 16   // the traced block of the weight-gradient kernels
 #endif
@@ -33,6 +35,10 @@ __device__ unsigned long long ch_trace_buf[8][64];
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (blockIdx.x == CH_TRACE_WG && (threadIdx.x & 63) == 0 && (slot) < 64) ch_trace_buf[threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#define WG_REAL(slot)                                                                                          \
+  do {                                                                                                         \
+    if (blockIdx.x == CH_TRACE_WG && (threadIdx.x & 63) == 0) ch_trace_buf[threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #define CH_STAMP(slot)                                                                                         \
   do {                                                                                                         \
@@ -43,6 +49,8 @@ __device__ unsigned long long ch_trace_buf[8][64];
 #else
 #define CH_STAMP(slot) do { } while (0)
 #define WG_STAMP(slot) do { } while (0)
+#define WG_REAL(slot) do { } while (0)
+#define WG_BLOCK(which) do { } while (0)
 #endif
 
 namespace mrl {
@@ -91,6 +99,8 @@ struct ChainBwdP {
   float* dz[2][CH_MAXL];       // [rows_pad][units] d loss / d pre-activation
   float* dy[2][CH_MAXL];       // [rows_pad][units] d loss / d LayerNorm output (its column sums are d beta, with x-hat d gamma); null for plain towers
   int natural;                 // Wn points at the row-major parameter tensors themselves ([wn_rows][units]), not at re-blocked copies
+  float* colblk[2][CH_MAXL];   // [blocks][3][units] column sums of the block's 16 rows: d gamma (dY * x-hat), d beta (dY), d bias (dZ); or null:
+                               // then dY goes to memory (dy) and the weight-gradient launch sums the columns
   int wn_rows[2][CH_MAXL];     // rows of Wn (the width of the layer above; the head's outputs for the last layer)
 };
 
@@ -464,7 +474,7 @@ __device__ __forceinline__ void chain_bwd_prefetch(const ChainBwdP& p, int tw, i
 
 template <int N, int KIND>
 __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int l, int K, float* zin, float* zout, float* red, int m0,
-                                                float (&wpre0)[32]) {
+                                                float (&wpre0)[32], float* ptile, float* colred) {
   constexpr int J = N >= 512 ? 4 : (N >= 256 ? 2 : 1);              // features per lane and load
   constexpr int GW = 16 * J;                                        // features per wave
   constexpr int NACT = N / GW < CH_WAVES ? N / GW : CH_WAVES;
@@ -586,29 +596,68 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
 #pragma unroll
     for (int q = 0; q < J; ++q) {
       *reinterpret_cast<f32x4*>(zout + ch_off(r16, (c0 >> 2) + q, ld)) = f32x4{dxh[4 * q], dxh[4 * q + 1], dxh[4 * q + 2], dxh[4 * q + 3]};
-      if constexpr (HAS_NORM)
+      if constexpr (HAS_NORM) {
         *reinterpret_cast<f32x4*>(zin + ch_off(r16, (c0 >> 2) + q, ld)) = f32x4{dyv[4 * q], dyv[4 * q + 1], dyv[4 * q + 2], dyv[4 * q + 3]};
+        if (p.colblk[tw][l])
+          *reinterpret_cast<f32x4*>(ptile + ch_off(r16, (c0 >> 2) + q, ld)) =
+              f32x4{dyv[4 * q] * xh[4 * q], dyv[4 * q + 1] * xh[4 * q + 1], dyv[4 * q + 2] * xh[4 * q + 2], dyv[4 * q + 3] * xh[4 * q + 3]};
+      }
     }
   }
   CH_STAMP(4 * (p.n_layers - 1 - l) + 3);
-  __syncthreads();   // both tiles complete, the exchange buffer reusable
+  __syncthreads();   // the tiles are complete, the exchange buffer reusable
   CH_STAMP(4 * (p.n_layers - 1 - l) + 4);
-  ch_copy_out<N>(tid, zout, ld, p.dz[tw][l], m0, 0x7fffffff);
-  if constexpr (HAS_NORM) ch_copy_out<N>(tid, zin, ld, p.dy[tw][l], m0, 0x7fffffff);
+  if (!p.colblk[tw][l]) {
+    ch_copy_out<N>(tid, zout, ld, p.dz[tw][l], m0, 0x7fffffff);
+    if constexpr (HAS_NORM) ch_copy_out<N>(tid, zin, ld, p.dy[tw][l], m0, 0x7fffffff);
+    return;
+  }
+  // dZ to memory as whole rows, and the column sums of the block's 16 rows on the way: a thread's pieces all lie in one 4-column
+  // chunk (512 is a multiple of the chunks per row), so it sums them in registers; the threads that share a chunk are combined
+  // in a fixed order through LDS
+  constexpr int CPR = N / 4, PIECES = CH_ROWS * CPR, NQ = HAS_NORM ? 3 : 1;
+  constexpr int TSH = (PIECES < 64 * CH_WAVES ? PIECES : 64 * CH_WAVES) / CPR;   // threads that share a chunk
+  f32x4 sz = {0.f, 0.f, 0.f, 0.f}, sb = sz, sg = sz;
+#pragma unroll
+  for (int c = tid; c < PIECES; c += 64 * CH_WAVES) {
+    const int r = c / CPR, ch = c % CPR;
+    const f32x4 vz = *reinterpret_cast<const f32x4*>(zout + ch_off(r, ch, ld));
+    *reinterpret_cast<f32x4*>(p.dz[tw][l] + (int64_t)(m0 + r) * N + ch * 4) = vz;
+    sz += vz;
+    if constexpr (HAS_NORM) {
+      sb += *reinterpret_cast<const f32x4*>(zin + ch_off(r, ch, ld));
+      sg += *reinterpret_cast<const f32x4*>(ptile + ch_off(r, ch, ld));
+    }
+  }
+  f32x4* cr = reinterpret_cast<f32x4*>(colred);   // [NQ][512]
+  if (tid < PIECES) {
+    cr[tid] = sz;
+    if constexpr (HAS_NORM) { cr[512 + tid] = sb; cr[1024 + tid] = sg; }
+  }
+  __syncthreads();
+  if (tid < NQ * CPR) {
+    const int q = tid / CPR, ch = tid - q * CPR;
+    f32x4 s = cr[q * 512 + ch];
+#pragma unroll
+    for (int k = 1; k < TSH; ++k) s += cr[q * 512 + k * CPR + ch];
+    const int slot = q == 0 ? 2 : (q == 1 ? 1 : 0);   // order of the partials: d gamma, d beta, d bias
+    *reinterpret_cast<f32x4*>(p.colblk[tw][l] + ((int64_t)blockIdx.x * 3 + slot) * N + ch * 4) = s;
+  }
 }
 
 // The backward chain of the block's 16 rows from the head seeds in tile `cur` ([16][32], swizzled like every tile); wpre0 holds the
 // first register group of the last layer (chain_bwd_prefetch).
 template <int KIND>
-__device__ __forceinline__ void chain_bwd_body(const ChainBwdP& p, float* red, float* cur, float* nxt, int tw, int m0, float (&wpre0)[32]) {
+__device__ __forceinline__ void chain_bwd_body(const ChainBwdP& p, float* red, float* cur, float* nxt, int tw, int m0, float (&wpre0)[32], float* ptile,
+                                               float* colred) {
   int K = 32;
   for (int l = p.n_layers - 1; l >= 0; --l) {
     switch (p.units[l]) {
-      case 512: chain_bwd_layer<512, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 256: chain_bwd_layer<256, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 128: chain_bwd_layer<128, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      case 64: chain_bwd_layer<64, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
-      default: chain_bwd_layer<32, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0); break;
+      case 512: chain_bwd_layer<512, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0, ptile, colred); break;
+      case 256: chain_bwd_layer<256, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0, ptile, colred); break;
+      case 128: chain_bwd_layer<128, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0, ptile, colred); break;
+      case 64: chain_bwd_layer<64, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0, ptile, colred); break;
+      default: chain_bwd_layer<32, KIND>(p, tw, l, K, cur, nxt, red, m0, wpre0, ptile, colred); break;
     }
     float* t = cur; cur = nxt; nxt = t;
     K = p.units[l];
@@ -633,7 +682,8 @@ __global__ __launch_bounds__(64 * CH_WAVES) void chain_bwd_kernel(const ChainBwd
     *reinterpret_cast<f32x4*>(cur + ch_off(r, ch, p.ld)) = v;
   }
   __syncthreads();
-  chain_bwd_body<KIND>(p, red, cur, nxt, tw, m0, wpre0);
+  float* ptile = nxt + CH_ROWS * p.ld;   // dY * x-hat of the layer, then the exchange of the column sums (only with colblk)
+  chain_bwd_body<KIND>(p, red, cur, nxt, tw, m0, wpre0, ptile, ptile + CH_ROWS * p.ld);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -654,6 +704,7 @@ struct ChainPpoP {
 
 constexpr int CH_TS = 33;                                                       // row stride of the head-output tile
 constexpr int CH_HEADS_F = CH_ROWS * CH_TS + 16 * MRL_NMETRIC * 2;    // floats of LDS behind the two activation tiles
+constexpr int CH_COLRED_F = 3 * 512 * 4;                              // floats of the column-sum exchange of the backward chain
 
 // head pre-activations of the block's rows: T[row][col] = h[row] . Wh[col] + bias[col], 32 columns (zero weights past the head)
 __device__ __forceinline__ void chain_heads_gemm(const float* WhB, bool natural, const float* bias, int Nv, int K, const float* hin, int ld, float* T) {
@@ -866,7 +917,8 @@ __global__ __launch_bounds__(64 * CH_WAVES) void ppo_chain_kernel(const ChainPpo
     for (int w = 0; w < 16; ++w) s += red2[w * MRL_NMETRIC + tid];
     p.h.metric_part[((int64_t)blockIdx.x * 2 + tw) * MRL_NMETRIC + tid] = s;
   }
-  chain_bwd_body<KIND>(p.b, red, nxt, cur, tw, m0, wpre0);
+  float* ptile = reinterpret_cast<float*>(red2 + 16 * MRL_NMETRIC);
+  chain_bwd_body<KIND>(p.b, red, nxt, cur, tw, m0, wpre0, ptile, ptile + CH_ROWS * ld);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1153,31 +1205,35 @@ struct WgTileDesc {
   const float* dy;       // [M][u] or null
   const float* xout;     // [M][u] x-hat of this layer (with dy)
   float* colpart;        // [nsplit][3][u] d gamma, d beta, d bias partial column sums, or null
-  int u, in, bn;         // bn: 128 or 64 columns per tile
+  int u, in, bm, bn;     // tile rows x columns: 128 x 128, 128 x 64 or 32 x 128
   int tiles_n, tiles, nsplit, task0;
 };
-struct WgTileP { WgTileDesc d[WG_MAXDESC]; int nd, ntasks, M; };
+// Tasks behind the tiles: the column sums the backward chain left per 16-row block ([nblk][3 u] per layer) are summed in `groups`
+// groups of consecutive blocks, so that the reduction that builds the gradient vector sees a few slabs per tensor.
+struct WgColDesc { const float* src; float* dst; int n4, nblk, groups, task0; };   // n4: 16-byte chunks of a slab (3 u / 4)
+struct WgTileP { WgTileDesc d[WG_MAXDESC]; int nd, ntasks, M; WgColDesc cd[2 * CH_MAXL]; int ncd; };
 constexpr int WT_LD = 132;                       // floats per staged row: 128 + 4, so that the four k-groups of a read start on different banks
 constexpr int WT_ROWS = 32;                      // rows per stage
 constexpr int WT_LDS_F = 2 * 2 * WT_ROWS * WT_LD;   // floats: two stages of two operands
 
-template <int BN>
+// Tile shapes (rows x columns): 128 x 128 (MT 4, NT 2), 128 x 64 (MT 2, NT 2), 32 x 128 (MT 2, NT 1: the heads' 32 rows).
+template <int BN, int MT, int NT>
 __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDesc& d, int split, int m0, int n0, float* lds) {
-  constexpr int WN = BN == 128 ? 4 : 2, WM = 8 / WN;   // waves along the columns / rows of the tile
-  constexpr int MT = 128 / WM / 16;                    // rows per lane and 4-row step: wave tile (16 MT) x 32
+  constexpr int WN = BN / (16 * NT), WM = 8 / WN;      // waves along the columns / rows of the tile; wave tile (16 MT) x (16 NT)
+  constexpr int BM = WM * 16 * MT;
   float* As = lds;
   float* Bs = lds + 2 * WT_ROWS * WT_LD;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15, kg = lane >> 4;
-  const int wm0 = (wave / WN) * (16 * MT), wn0 = (wave % WN) * 32;
+  const int wm0 = (wave / WN) * (16 * MT), wn0 = (wave % WN) * (16 * NT);
   const int G = (p.M + WT_ROWS - 1) / WT_ROWS;
   const int s0 = (int)((int64_t)split * G / d.nsplit), s1 = (int)((int64_t)(split + 1) * G / d.nsplit);
   const int nst = s1 - s0, k0 = s0 * WT_ROWS;
   const int cols = (n0 == 0 && d.colpart) ? (d.dy ? 2 : 1) : 0;
   // loader role of this thread: rows lr and lr + 16 of a stage, 4 columns from col4
   const int lr = tid >> 5, col4 = (tid & 31) * 4;
-  const bool loadsB = col4 < BN;
+  const bool loadsA = col4 < BM, loadsB = col4 < BN;
   // rows past the batch read as zeros (descriptor bounds); columns past a matrix's width wrap into the next row and only feed
   // outputs that are not stored
   const rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dz), 0, p.M * d.u * 4, 0x00020000);
@@ -1186,19 +1242,21 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
   const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy ? d.xout : d.dz), 0, p.M * d.u * 4, 0x00020000);
   const int voffZ = (lr * d.u + m0 + col4) * 4, voffX = (lr * d.in + n0 + col4) * 4;
   const int h16Z = 16 * d.u * 4, h16X = 16 * d.in * 4;     // bytes per 16 rows
-  f32x4 acc[MT][2];
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int j = 0; j < MT; ++j)
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) acc[j][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t2 = 0; t2 < NT; ++t2) acc[j][t2] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 cz = {0.f, 0.f, 0.f, 0.f}, cg = cz, cb = cz;
   // two register sets: the loads of a stage are issued two stages before its rows go to LDS
   struct Regs { f32x4 a[2], b[2], y[2], o[2]; };
   Regs r0, r1;
   auto load_stage = [&](int s, Regs& r) {
     const int sz = (k0 + s * WT_ROWS) * d.u * 4, sx = (k0 + s * WT_ROWS) * d.in * 4;
-    r.a[0] = ch_load16(rsZ, voffZ, sz);
-    r.a[1] = ch_load16(rsZ, voffZ, sz + h16Z);
+    if (loadsA) {
+      r.a[0] = ch_load16(rsZ, voffZ, sz);
+      r.a[1] = ch_load16(rsZ, voffZ, sz + h16Z);
+    }
     if (loadsB) {
       r.b[0] = ch_load16(rsX, voffX, sx);
       r.b[1] = ch_load16(rsX, voffX, sx + h16X);
@@ -1211,15 +1269,17 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
     }
   };
   auto store_stage = [&](int buf, const Regs& r) {
-    float* a = As + buf * WT_ROWS * WT_LD + lr * WT_LD + col4;
-    *reinterpret_cast<f32x4*>(a) = r.a[0];
-    *reinterpret_cast<f32x4*>(a + 16 * WT_LD) = r.a[1];
+    if (loadsA) {
+      float* a = As + buf * WT_ROWS * WT_LD + lr * WT_LD + col4;
+      *reinterpret_cast<f32x4*>(a) = r.a[0];
+      *reinterpret_cast<f32x4*>(a + 16 * WT_LD) = r.a[1];
+    }
     if (loadsB) {
       float* b = Bs + buf * WT_ROWS * WT_LD + lr * WT_LD + col4;
       *reinterpret_cast<f32x4*>(b) = r.b[0];
       *reinterpret_cast<f32x4*>(b + 16 * WT_LD) = r.b[1];
     }
-    if (cols >= 1) cz += r.a[0] + r.a[1];
+    if (cols >= 1 && loadsA) cz += r.a[0] + r.a[1];
     if (cols == 2) {
       cg += r.y[0] * r.o[0] + r.y[1] * r.o[1];
       cb += r.y[0] + r.y[1];
@@ -1227,7 +1287,7 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
   };
   auto compute_stage = [&](int buf) {
     const float* a = As + buf * WT_ROWS * WT_LD + kg * WT_LD + wm0 + MT * i16;
-    const float* b = Bs + buf * WT_ROWS * WT_LD + kg * WT_LD + wn0 + 2 * i16;
+    const float* b = Bs + buf * WT_ROWS * WT_LD + kg * WT_LD + wn0 + NT * i16;
 #pragma unroll
     for (int ks = 0; ks < WT_ROWS / 4; ++ks) {
       float av[MT];
@@ -1239,14 +1299,21 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
         const f32x2 v = *reinterpret_cast<const f32x2*>(a + ks * 4 * WT_LD);
         av[0] = v[0]; av[1] = v[1];
       }
-      const f32x2 bv = *reinterpret_cast<const f32x2*>(b + ks * 4 * WT_LD);
+      float bv[NT];
+      if constexpr (NT == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(b + ks * 4 * WT_LD);
+        bv[0] = v[0]; bv[1] = v[1];
+      } else {
+        bv[0] = b[ks * 4 * WT_LD];
+      }
 #pragma unroll
       for (int j = 0; j < MT; ++j)
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) acc[j][t2] = ch_mfma(av[j], bv[t2], acc[j][t2]);
+        for (int t2 = 0; t2 < NT; ++t2) acc[j][t2] = ch_mfma(av[j], bv[t2], acc[j][t2]);
     }
   };
   WG_STAMP(0);
+  WG_REAL(50);
   if (nst > 0) {
     load_stage(0, r0);
     if (nst > 1) load_stage(1, r1);
@@ -1289,19 +1356,23 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
       }
     }
   }
-  // lane (c = i16, kg) holds rows m0 + wm0 + MT (4 kg + r) + j, columns n0 + wn0 + 2 c + (0, 1) in acc[j][0..1][r]
+  // lane (c = i16, kg) holds rows m0 + wm0 + MT (4 kg + r) + j, columns n0 + wn0 + NT c + (0 .. NT-1) in acc[j][..][r]
   float* out = d.slab + (int64_t)split * d.u * d.in;
-  const int col = n0 + wn0 + 2 * i16;
+  const int col = n0 + wn0 + NT * i16;
   if (col < d.in) {
 #pragma unroll
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = m0 + wm0 + MT * (4 * kg + r) + j;
-        if (orow < d.u) *reinterpret_cast<f32x2*>(out + (int64_t)orow * d.in + col) = f32x2{acc[j][0][r], acc[j][1][r]};
+        if (orow < d.u) {
+          if constexpr (NT == 2) *reinterpret_cast<f32x2*>(out + (int64_t)orow * d.in + col) = f32x2{acc[j][0][r], acc[j][1][r]};
+          else out[(int64_t)orow * d.in + col] = acc[j][0][r];
+        }
       }
   }
   WG_STAMP(40);
+  WG_REAL(51);
   if (cols >= 1) {
     // column sums: the 16 loader rows of a column chunk are combined in a fixed order through LDS (all waves are past the last barrier)
     f32x4* red = reinterpret_cast<f32x4*>(lds);            // [3][16][32 chunks]
@@ -1312,7 +1383,7 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
     }
     __syncthreads();
     const int q = tid >> 5, ch = tid & 31;                 // quantity 0 d bias, 1 d gamma, 2 d beta
-    if (q < (cols == 2 ? 3 : 1) && m0 + 4 * ch < d.u) {
+    if (q < (cols == 2 ? 3 : 1) && 4 * ch < BM && m0 + 4 * ch < d.u) {
       f32x4 s = red[(q * 16) * 32 + ch];
 #pragma unroll
       for (int r = 1; r < 16; ++r) s += red[(q * 16 + r) * 32 + ch];
@@ -1325,19 +1396,47 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
 
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileP p) {
   extern __shared__ __attribute__((aligned(16))) float wt_lds[];
+  WG_BLOCK(0);
   // blocks are handed to the 8 XCDs in turn: remapped so that every XCD works on one contiguous eighth of the task list (the
   // tiles of one row range read the same rows)
   const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
   const int task = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  if (task >= p.ntasks) {
+    int ci = 0;
+    for (int q = 1; q < p.ncd; ++q)
+      if (task >= p.cd[q].task0) ci = q;
+    const WgColDesc& cdsc = p.cd[ci];
+    const int idx = (task - cdsc.task0) * 512 + threadIdx.x;
+    const int grp = idx / cdsc.n4, ch = idx - grp * cdsc.n4;
+    if (grp >= cdsc.groups) return;
+    const int per = (cdsc.nblk + cdsc.groups - 1) / cdsc.groups;
+    const int b0 = grp * per, b1 = min(cdsc.nblk, b0 + per);
+    const float* src = cdsc.src + 4 * (int64_t)ch;
+    const int64_t stride = 4 * (int64_t)cdsc.n4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 16 <= b1; b += 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (b + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(src + b * stride);
+    *reinterpret_cast<f32x4*>(cdsc.dst + grp * stride + 4 * ch) = s;
+    return;
+  }
   int di = 0;
   for (int q = 1; q < p.nd; ++q)
     if (task >= p.d[q].task0) di = q;
   const WgTileDesc& d = p.d[di];
   const int local = task - d.task0;
   const int split = local / d.tiles, tile = local - split * d.tiles;
-  const int m0 = (tile / d.tiles_n) * 128, n0 = (tile % d.tiles_n) * d.bn;
-  if (d.bn == 128) wgrad_tile_task<128>(p, d, split, m0, n0, wt_lds);
-  else wgrad_tile_task<64>(p, d, split, m0, n0, wt_lds);
+  const int m0 = (tile / d.tiles_n) * d.bm, n0 = (tile % d.tiles_n) * d.bn;
+  if (d.bm == 32) wgrad_tile_task<128, 2, 1>(p, d, split, m0, n0, wt_lds);
+  else if (d.bn == 128) wgrad_tile_task<128, 4, 2>(p, d, split, m0, n0, wt_lds);
+  else wgrad_tile_task<64, 2, 2>(p, d, split, m0, n0, wt_lds);
+  WG_BLOCK(1);
 }
 
 }  // namespace mrl

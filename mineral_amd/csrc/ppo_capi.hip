@@ -164,7 +164,7 @@ static int chain_mask() {
 // MRL_CHAIN bit 8: the chain kernels read the weights from the parameter tensors as they are (no re-blocked copies, no launch that makes them)
 static bool chain_natural() { return (chain_mask() & 8) != 0; }
 static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
-  return (chain_mask() & bit) != 0 && rows <= MRL_SMALL_M && net->n_layers <= CH_MAXL;
+  return (chain_mask() & bit) != 0 && rows <= MRL_SMALL_M && net->n_layers <= CH_MAXL && net->obs_dim <= 512;   // LDS tiles of at most 512 columns
 }
 // 64 x 64 weight-gradient tiles of one tower (layers + head) and the row ranges they are split into: about 1,024 wave tasks
 // for two towers (one per SIMD: the launch keeps one block of four waves per CU), at least 64 rows each, whole multiples of 32 rows
@@ -187,26 +187,32 @@ static void chain_wgrad_split(const mrl_net* net, const int* in_dim, int64_t row
 // Block-tile weight gradients (wgrad_tile_kernel; MRL_CHAIN bit 16 keeps the wave-tile kernel): column blocks of 64 for inputs of at
 // most 64 columns, else 128; row ranges per gradient so that the launch has at most one block per CU (MRL_CHAIN_TASKS, default 256)
 // and every block about the same number of MFMAs: gradients with 64-column tiles get half as many ranges.  Index n_layers = the heads.
-struct ChainWgPlan { int bn[MRL_MAX_LAYERS + 1], nsplit[MRL_MAX_LAYERS + 1]; };
+struct ChainWgPlan { int bm[MRL_MAX_LAYERS + 1], bn[MRL_MAX_LAYERS + 1], nsplit[MRL_MAX_LAYERS + 1]; };
 static bool chain_tile_wgrad(const mrl_net* net, int64_t rows) { return chain_ok(net, rows, 3) && (chain_mask() & 16) == 0; }
 static ChainWgPlan chain_wgrad_plan(const mrl_net* net, const int* in_dim, int64_t rows) {
   static const int target = [] { const char* e = getenv("MRL_CHAIN_TASKS"); return e ? atoi(e) : 256; }();
   ChainWgPlan pl;
   const int nl = net->n_layers;
-  int tiles[MRL_MAX_LAYERS + 1];
+  int tiles[MRL_MAX_LAYERS + 1], cost[MRL_MAX_LAYERS + 1];   // cost of a tile in quarters of a 128 x 128 one
   for (int l = 0; l <= nl; ++l) {
     const int u = l == nl ? 32 : net->units[l], in = l == nl ? net->units[nl - 1] : in_dim[l];
+    pl.bm[l] = (u <= 32 && in > 64) ? 32 : 128;
     pl.bn[l] = in <= 64 ? 64 : 128;
-    tiles[l] = (int)(cdiv(u, 128) * cdiv(in, pl.bn[l]));
+    cost[l] = pl.bm[l] == 32 ? 1 : (pl.bn[l] == 64 ? 2 : 4);
+    tiles[l] = (int)(cdiv(u, pl.bm[l]) * cdiv(in, pl.bn[l]));
   }
   const int maxs = (int)std::max<int64_t>(1, cdiv(rows, 32) / 2);   // at least 64 rows per range
+  // the launch also carries the blocks that sum the backward chain's column sums (WgColDesc): everything in one wave of blocks
+  int col_blocks = 0;
+  for (int l = 0; l < nl; ++l) col_blocks += 2 * (int)cdiv((int64_t)(3 * net->units[l] / 4) * std::min<int64_t>(8, cdiv(rows, CH_ROWS)), 512);
+  auto splits_of = [&](int l, int sp) { return std::max(1, (sp * cost[l] + 3) / 4); };
   int best = 1;
   for (int sp = 1; sp <= maxs; ++sp) {
     int total = 0;
-    for (int l = 0; l <= nl; ++l) total += 2 * tiles[l] * (pl.bn[l] == 128 ? sp : (sp + 1) / 2);
-    if (total <= target) best = sp;
+    for (int l = 0; l <= nl; ++l) total += 2 * tiles[l] * splits_of(l, sp);
+    if (total + col_blocks <= target) best = sp;
   }
-  for (int l = 0; l <= nl; ++l) pl.nsplit[l] = pl.bn[l] == 128 ? best : (best + 1) / 2;
+  for (int l = 0; l <= nl; ++l) pl.nsplit[l] = splits_of(l, best);
   return pl;
 }
 
@@ -235,6 +241,8 @@ struct Workspace {
   int64_t xnorm;                   // small batches: the normalised input rows
   int64_t seeds[2];
   int64_t colpart[2][MRL_MAX_LAYERS];
+  int64_t colblk[2][MRL_MAX_LAYERS];   // small batches, block-tile weight gradients: [16-row blocks][3][u] column sums from the backward chain
+  int col_groups;        // ... summed in this many groups into colpart
   int64_t colpart_h[2];  // small batches: [row ranges][3][32] column sums of the head seeds (head-bias gradients) from the weight-gradient launch
   bool chain_bwd;        // the backward pass of this row count runs the chain kernels and the one-launch weight gradient
   int64_t slab[2][MRL_MAX_LAYERS], slab_h[2];
@@ -274,7 +282,12 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       w->dz[tw][l] = o; o = align64(o + rows_pad * u);
       if (chain_bwd) { w->dy[tw][l] = o; o = align64(o + rows_pad * u); }
       if (chain_fb) { w->hact[tw][l] = o; o = align64(o + rows_pad * u); }
-      if (chain_bwd) w->rowblocks[l] = tile_wg ? tp.nsplit[l] : ch_nsplit;                    // column partials per row range of the weight-gradient launch
+      if (tile_wg) {   // column sums per 16-row block from the backward chain, summed in at most 8 groups by the weight-gradient launch
+        const int64_t nblk = cdiv(rows, CH_ROWS);
+        w->col_groups = (int)std::min<int64_t>(8, nblk);
+        w->colblk[tw][l] = o; o = align64(o + nblk * 3 * u);
+        w->rowblocks[l] = w->col_groups;
+      } else if (chain_bwd) w->rowblocks[l] = ch_nsplit;                                      // column partials per row range of the weight-gradient launch
       else if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
       else w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
@@ -707,6 +720,8 @@ static int chain_ld(const mrl_net* net, int in_dim) {
   return (m + 63) & ~63;
 }
 static size_t chain_lds_bytes(int ld) { return (size_t)(CH_RED + 2 * CH_ROWS * ld) * sizeof(float); }
+// the backward chain adds a third tile and the exchange of its column sums
+static size_t chain_bwd_extra_lds(int ld) { return (size_t)(CH_ROWS * ld + CH_COLRED_F) * sizeof(float); }
 // the widest networks need a little more dynamic LDS than the 64 KB a kernel may ask for by default
 static void chain_allow_lds() {
   static const bool once = [] {
@@ -715,7 +730,7 @@ static void chain_allow_lds() {
                          reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
                          reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(ppo_chain_kernel<CH_PLAIN_ELU>),
                          reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel)};
-    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)once;
@@ -1973,6 +1988,7 @@ static void fill_chain_bwd(const mrl_net* net, const ParamLayout& L, const Works
       p.be[t][l] = L.has_norm ? params + L.be[tw][l] : nullptr;
       p.dz[t][l] = ws + W.dz[tw][l];
       p.dy[t][l] = L.has_norm ? ws + W.dy[tw][l] : nullptr;
+      p.colblk[t][l] = chain_tile_wgrad(net, mb) ? ws + W.colblk[tw][l] : nullptr;
     }
   }
   for (int t = 0; t < towers; ++t) p.seeds[t] = ws + W.seeds[tw0 + t];
@@ -1994,7 +2010,7 @@ static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Wor
     chain_allow_lds();
     MRL_PROF_STREAM("mrl::chain_bwd_kernel", s);
     const dim3 grid((unsigned)cdiv(mb, CH_ROWS), towers);
-    const size_t lds = chain_lds_bytes(p.ld);
+    const size_t lds = chain_lds_bytes(p.ld) + chain_bwd_extra_lds(p.ld);
     if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
     else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
     else hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
@@ -2022,17 +2038,25 @@ static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const W
         d.dz = head ? ws + W.seeds[tw] : ws + W.dz[tw][l];
         d.xin = (l == 0) ? (obs_mean ? ws + W.xnorm : x) : ws + W.hact[tw][l - 1];
         d.slab = head ? ws + W.slab_h[tw] : ws + W.slab[tw][l];
-        d.colpart = head ? ws + W.colpart_h[tw] : ws + W.colpart[tw][l];
-        if (!head && L.has_norm) { d.dy = ws + W.dy[tw][l]; d.xout = ws + W.xhat[tw][l]; }
-        d.bn = pl.bn[l];
+        d.colpart = head ? ws + W.colpart_h[tw] : nullptr;   // the layers' column sums come from the backward chain (colblk)
+        d.bm = pl.bm[l]; d.bn = pl.bn[l];
         d.nsplit = pl.nsplit[l];
         d.tiles_n = (int)cdiv(d.in, d.bn);
-        d.tiles = (int)cdiv(d.u, 128) * d.tiles_n;
+        d.tiles = (int)cdiv(d.u, d.bm) * d.tiles_n;
         d.task0 = task;
         task += d.tiles * d.nsplit;
       }
     }
     q.ntasks = task;
+    const int nblk = (int)cdiv(mb, CH_ROWS);
+    for (int t = 0; t < towers; ++t)
+      for (int l = 0; l < nl; ++l) {
+        WgColDesc& cd = q.cd[q.ncd++];
+        cd.src = ws + W.colblk[tw0 + t][l]; cd.dst = ws + W.colpart[tw0 + t][l];
+        cd.n4 = 3 * net->units[l] / 4; cd.nblk = nblk; cd.groups = W.col_groups;
+        cd.task0 = task;
+        task += (int)cdiv((int64_t)cd.n4 * cd.groups, 512);
+      }
     MRL_PROF_STREAM("mrl::wgrad_tile_kernel", s);
     hipLaunchKernelGGL(wgrad_tile_kernel, dim3((unsigned)task), dim3(512), WT_LDS_F * sizeof(float), s, q);
     return;
@@ -2471,7 +2495,7 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
     {
       MRL_PROF_STREAM("mrl::ppo_chain_kernel", s);
       const dim3 grid((unsigned)(p.f.rows_written / CH_ROWS), 2);
-      const size_t lds = chain_lds_bytes(p.f.ld) + CH_HEADS_F * sizeof(float);
+      const size_t lds = chain_lds_bytes(p.f.ld) + CH_HEADS_F * sizeof(float) + chain_bwd_extra_lds(p.f.ld);
       if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
       else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
       else hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);

@@ -115,16 +115,17 @@ int main(int argc, char** argv) {
   WgTileP wt; memset(&wt, 0, sizeof(wt));
   wt.M = M;
   int ttask = 0;
-  const int sfull = argc > 4 ? atoi(argv[4]) : 9;
+  const int sfull = argc > 4 ? atoi(argv[4]) : 10;
   for (int i = 0; i < w.nd; ++i) {
     const WgDesc& o = w.d[i];
     WgTileDesc& d = wt.d[wt.nd++];
     d.dz = o.dz; d.xin = o.xin; d.dy = o.dy; d.xout = o.xout; d.u = o.u; d.in = o.in;
+    d.bm = (d.u <= 32 && d.in > 64) ? 32 : 128;
     d.bn = d.in <= 64 ? 64 : 128;
-    d.nsplit = d.bn == 128 ? sfull : (sfull + 1) / 2;
+    d.nsplit = d.bm == 32 ? (sfull + 3) / 4 : (d.bn == 128 ? sfull : (sfull + 1) / 2);
     d.slab = dalloc((size_t)d.nsplit * d.u * d.in, 0, 0.f);
     d.colpart = dalloc((size_t)d.nsplit * 3 * d.u, 0, 0.f);
-    d.tiles_n = (d.in + d.bn - 1) / d.bn; d.tiles = ((d.u + 127) / 128) * d.tiles_n; d.task0 = ttask; ttask += d.tiles * d.nsplit;
+    d.tiles_n = (d.in + d.bn - 1) / d.bn; d.tiles = ((d.u + d.bm - 1) / d.bm) * d.tiles_n; d.task0 = ttask; ttask += d.tiles * d.nsplit;
   }
   wt.ntasks = ttask;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -220,8 +221,20 @@ int main(int argc, char** argv) {
     for (int wv = 0; wv < 8; ++wv) {
       printf("  wave %d: %6lld |", wv, (long long)(h[wv][1] - h[wv][0]));
       for (int sl = 2; sl <= 17; ++sl) printf(" %6lld", (long long)(h[wv][sl] - h[wv][0]));
-      printf("  | stores %6lld\n", (long long)(h[wv][40] - h[wv][0]));
+      printf("  | stores %6lld; %.0f MHz\n", (long long)(h[wv][40] - h[wv][0]), 100.0 * (double)(h[wv][40] - h[wv][0]) / (double)(h[wv][51] - h[wv][50]));
     }
+  }
+  {
+    CK(hipDeviceSynchronize());
+    run_wt();
+    CK(hipDeviceSynchronize());
+    static unsigned long long hb[1024][2];
+    CK(hipMemcpyFromSymbol(hb, HIP_SYMBOL(ch_block_clk), sizeof(hb)));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < ttask; ++i) { t0 = std::min(t0, hb[i][0]); t1 = std::max(t1, hb[i][1]); }
+    printf("wgrad_tile blocks: first entry to last exit %.2f us; per block [start offset us, duration us]:\n", (t1 - t0) / 100.0);
+    for (int i = 0; i < ttask; ++i) printf("%s%5.2f,%5.2f", i % 8 ? "  " : "\n  ", (hb[i][0] - t0) / 100.0, (hb[i][1] - hb[i][0]) / 100.0);
+    printf("\n");
   }
 #endif
   // back-to-back sequence as in a step
