@@ -4,6 +4,7 @@
 #include "gemm.hip.h"
 #include "split_bf16.hip.h"
 #include "chain.hip.h"
+#include "wgrad_group.hip.h"
 
 #include <hip/hip_ext.h>
 #include <math.h>
@@ -187,16 +188,23 @@ static void chain_wgrad_split(const mrl_net* net, const int* in_dim, int64_t row
 // Block-tile weight gradients (wgrad_tile_kernel; MRL_CHAIN bit 16 keeps the wave-tile kernel): column blocks of 64 for inputs of at
 // most 64 columns, else 128; row ranges per gradient so that the launch has at most one block per CU (MRL_CHAIN_TASKS, default 256)
 // and every block about the same number of MFMAs: gradients with 64-column tiles get half as many ranges.  Index n_layers = the heads.
-struct ChainWgPlan { int bm[MRL_MAX_LAYERS + 1], bn[MRL_MAX_LAYERS + 1], nsplit[MRL_MAX_LAYERS + 1]; };
+struct ChainWgPlan { int bm[MRL_MAX_LAYERS + 1], bn[MRL_MAX_LAYERS + 1], nsplit[MRL_MAX_LAYERS + 1]; bool split_bf16; };
 static bool chain_tile_wgrad(const mrl_net* net, int64_t rows) { return chain_ok(net, rows, 3) && (chain_mask() & 16) == 0; }
 static ChainWgPlan chain_wgrad_plan(const mrl_net* net, const int* in_dim, int64_t rows) {
   static const int target = [] { const char* e = getenv("MRL_CHAIN_TASKS"); return e ? atoi(e) : 256; }();
   ChainWgPlan pl;
   const int nl = net->n_layers;
   int tiles[MRL_MAX_LAYERS + 1], cost[MRL_MAX_LAYERS + 1];   // cost of a tile in quarters of a 128 x 128 one
+  // every gradient with 64 or a multiple of 128 columns: the launch on the bf16 matrix cores (wgrad_group_kernel, tiles of 128 rows;
+  // MRL_CHAIN bit 32 keeps the fp32 one)
+  pl.split_bf16 = (chain_mask() & 32) == 0;
+  for (int l = 0; l <= nl; ++l) {
+    const int in = l == nl ? net->units[nl - 1] : in_dim[l];
+    if (in != 64 && in % 128 != 0) pl.split_bf16 = false;
+  }
   for (int l = 0; l <= nl; ++l) {
     const int u = l == nl ? 32 : net->units[l], in = l == nl ? net->units[nl - 1] : in_dim[l];
-    pl.bm[l] = (u <= 32 && in > 64) ? 32 : 128;
+    pl.bm[l] = (u <= 32 && in > 64 && !pl.split_bf16) ? 32 : 128;
     pl.bn[l] = in <= 64 ? 64 : 128;
     cost[l] = pl.bm[l] == 32 ? 1 : (pl.bn[l] == 64 ? 2 : 4);
     tiles[l] = (int)(cdiv(u, pl.bm[l]) * cdiv(in, pl.bn[l]));
@@ -729,7 +737,8 @@ static void chain_allow_lds() {
                          reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_SILU>),
                          reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
                          reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(ppo_chain_kernel<CH_PLAIN_ELU>),
-                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel)};
+                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel),
+                         reinterpret_cast<const void*>(wgrad_group_kernel)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
@@ -2057,6 +2066,11 @@ static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const W
         cd.task0 = task;
         task += (int)cdiv((int64_t)cd.n4 * cd.groups, 512);
       }
+    if (pl.split_bf16) {
+      MRL_PROF_STREAM("mrl::wgrad_group_kernel", s);
+      hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)task), dim3(512), WGG_LDS, s, q);
+      return;
+    }
     MRL_PROF_STREAM("mrl::wgrad_tile_kernel", s);
     hipLaunchKernelGGL(wgrad_tile_kernel, dim3((unsigned)task), dim3(512), WT_LDS_F * sizeof(float), s, q);
     return;
