@@ -181,6 +181,8 @@ def main():
     dt = time.perf_counter() - t0
     flat64 = agent.model.flat.double()
     param_checksum = [float(flat64.sum().item()), float((flat64 * flat64).sum().item())]   # run-to-run / rank-count comparisons
+    import hashlib
+    param_sha256 = hashlib.sha256(agent.model.flat.detach().cpu().numpy().tobytes()).hexdigest()   # every bit of every parameter
     dominant, dt_events = None, None
     if timing:
         # the same K steps once more with HIP events around every launch of the dominant kernel, on the stream it is launched
@@ -246,6 +248,7 @@ def main():
                    'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
     }
     out['param_checksum'] = param_checksum
+    out['param_sha256'] = param_sha256
     if multi:
         out['ranks_in_sync'] = in_sync
         out['rccl'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_seen': ranks_seen,

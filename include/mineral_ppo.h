@@ -181,7 +181,9 @@ int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, double count, 
  * results as mrl_gae_finish, but the scratch (per-block partial sums, sums, statistics) lives in a device array built
  * into the library: 786,688 bytes that every GPU the library runs on holds until the process ends.  At most 1,048,576
  * envs (MRL_EINVAL beyond that).  Allocates nothing.  The device that owns `stream` must be the current device.  All
- * calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+ * calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race.  The first call
+ * on a device looks up the array's address (which may load the library's code object on that device): make one call
+ * outside any stream capture before capturing. */
 int mrl_gae_finish_static(const mrl_rollout* buf, const float* last_values, double gamma, double tau,
                           const mrl_rms* value_rms, float* stats_out, void* stream);
 

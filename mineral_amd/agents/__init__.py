@@ -4,3 +4,4 @@ Third parties register with `mineral_amd.agents.MyAgent = MyAgent` (cf. examples
 from .agent import Agent
 from .ppo.ppo import PPO
 from .sac.sac import SAC
+from .template_agent import Template

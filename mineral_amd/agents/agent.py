@@ -2,6 +2,7 @@
 
 import os
 import re
+from contextlib import contextmanager
 
 import numpy as np
 import torch
@@ -64,6 +65,12 @@ class Agent:
         self.mini_epoch = -1
         self.agent_steps = 0
 
+    def get_actions(self, obs, sample: bool = True):
+        raise NotImplementedError          # agent.py:83-84
+
+    def explore_env(self, env, timesteps: int, random: bool = False, sample: bool = False):
+        raise NotImplementedError          # agent.py:86-87
+
     def train(self):
         raise NotImplementedError
 
@@ -88,6 +95,16 @@ class Agent:
         return Metrics(scores, tracker_len, env_render=self.env_render, **{k: v for k, v in dict(metrics_kwargs).items()
                                                                            if k in ('info_keys', 'save_video_every',
                                                                                     'save_video_consecutive')})
+
+    @contextmanager
+    def _as_metrics(self, new_metrics):
+        """agent.py:115-122: swap `self.metrics` for the duration of a block (evaluation)."""
+        old = self.metrics
+        self.metrics = new_metrics
+        try:
+            yield
+        finally:
+            self.metrics = old
 
     def _checkpoint_save(self, stat, stat_name='rewards', higher_better=True, sep=''):
         """agent.py:124-142: periodic + `latest.pth` symlink + one rolling best checkpoint."""
@@ -117,5 +134,20 @@ class Agent:
             obs = {'obs': obs}
         out = {}
         for k, v in obs.items():
-            out[k] = torch.tensor(v, device=self.device) if isinstance(v, np.ndarray) else v
+            if isinstance(v, np.ndarray):   # keys matching `cpu_obs_keys` stay on the host (agent.py:152)
+                out[k] = torch.tensor(v, device='cpu' if self.cpu_obs_keys.match(k) else self.device)
+            else:
+                out[k] = v
         return out
+
+    @staticmethod
+    def _handle_timeout(dones, info, timeout_keys=('time_outs', 'TimeLimit.truncated', 'truncated')):
+        """agent.py:158-167: an env that stopped on its time limit did not reach a terminal state (the first key found decides)."""
+        timeout_envs = None
+        for key in timeout_keys:
+            if key in info:
+                timeout_envs = info[key]
+                break
+        if timeout_envs is not None:
+            dones = dones * (~timeout_envs)
+        return dones

@@ -353,6 +353,7 @@ class PPO(Agent):
                 k += 1
             if self._dist is not None:
                 kl = parallel.unpack_scalar(self._grads_full[P:]) / (n_mb * self.rank_size)
+                self._grads_full[P:].zero_()   # the tail rides along in every all-reduce: zeros stay zeros until the next mini-epoch packs
             else:
                 kl = self._metrics[k0:k, 3].mean()
             avg_kls.append(kl)

@@ -39,6 +39,10 @@ _INFO_MODES = {'sum': 0, 'min': 1, 'max': 2, 'final': 3}
 class Metrics:
     """Episode scores and regex-selected per-env info keys (mineral/common/metrics.py:12-170) on the device.
 
+    All windows share one ring position (the reward window's): an info value of a finished episode lands at that episode's place
+    in the reward window.  That equals the reference's per-key deques as long as a key is present on every step from the
+    first episode on; a key that first appears later is placed by episode, not in a deque order of its own.
+
     `info_keys` = {'sum' | 'min' | 'max' | 'final' | 'scalar': regex}: every key of the observation dict that matches (re.match,
     like the reference) and holds one float per env is aggregated over the episode; finished episodes enter a window of the
     last `tracker_len` values whose mean `result()` reports as `{prefix}_infos/{key}_{mode}`.  Keys whose value is not one
@@ -70,6 +74,7 @@ class Metrics:
         self.episode_trackers = {'rewards': rewards, 'lengths': DeviceTracker(tracker_len, dev, head=rewards.head)}
         self._num_episodes = torch.zeros(1, dtype=torch.int64, device=dev)
         self._current_info = {}    # '{key}_{mode}' -> per-env running value (metrics.py:75)
+        self._info_born = {}       # '{key}_{mode}' -> episode count when the key was first seen
         self._extras = {}
 
     @property
@@ -101,6 +106,9 @@ class Metrics:
                     init = float('nan') if mode in ('min', 'max') else 0.0        # fmin / fmax skip NaN: the first value is taken as it is
                     self._current_info[name] = torch.full((n,), init, dtype=torch.float32, device=self.device)
                     self.episode_trackers[name] = DeviceTracker(self.tracker_len, self.device, head=self.episode_trackers['rewards'].head)
+                    # episodes finished before this key was first seen: the reference creates a key's Tracker when an episode first
+                    # finishes with it (metrics.py:104-107), so result() leaves the key out until then
+                    self._info_born[name] = self._num_episodes.clone()
                 # metrics.py:110-113 picks the restart value by the NAME: 0 when it contains 'sum' or 'final', NaN otherwise
                 reset_nan = 0 if ('sum' in name or 'final' in name) else 1
                 _hip.check(_hip.lib().mrl_info_track(_hip.ptr(x), _hip.ptr(d), n, code, reset_nan, _hip.ptr(self._current_info[name]),
@@ -133,6 +141,8 @@ class Metrics:
         for k, v in self.episode_trackers.items():
             if k in self.current_scores:          # rewards and lengths are reported by the agents themselves
                 continue
+            if k in self._info_born and int(self._num_episodes.item()) <= int(self._info_born[k].item()):
+                continue                          # no episode has finished since the key appeared: the reference has no Tracker for it yet
             metrics[f'{prefix}_infos/{k}'] = v.mean()
         for k, v in self._extras.items():
             metrics[f'{prefix}_extras/{k}'] = v

@@ -690,7 +690,8 @@ static unsigned short* launch_split_params(const ParamLayout& L, const Workspace
   for (int tw = 0; tw < L.n_towers; ++tw)
     for (int l = 0; l < nl; ++l) {
       const int rows = (int)((L.b[tw][l] - L.W[tw][l]) / L.in_dim[l]);   // at least the layer's outputs (the offset of b is padded to 4)
-      if (L.in_dim[l] % 16 == 0 && tab.n < MRL_MAX_SPLITDESC) tab.d[tab.n++] = SplitDesc{L.W[tw][l], rows, L.in_dim[l]};
+      static_assert(MRL_MAX_SPLITDESC >= 2 * MRL_MAX_LAYERS, "one descriptor per weight matrix of two towers");
+      if (L.in_dim[l] % 16 == 0) tab.d[tab.n++] = SplitDesc{L.W[tw][l], rows, L.in_dim[l]};
     }
   hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)cdiv(L.total, 256)), dim3(256), 0, s, params, L.total, planes, W.wplane_stride,
                      planes + 3 * W.wplane_stride, tab);
@@ -2368,8 +2369,8 @@ static int side_stream(SideStream** out) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= MRL_MAX_DEVICES) MRL_FAIL(MRL_EHIP, "hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
   SideStream& ss = g_side[dev];
-  if (!ss.s) {
-    static std::mutex mu;
+  {
+    static std::mutex mu;   // taken on every call: this path is an A/B variant, not the default launch structure
     std::lock_guard<std::mutex> lock(mu);
     if (!ss.s) {
       hipStream_t st = nullptr;

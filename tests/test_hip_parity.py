@@ -563,6 +563,50 @@ def test_observation_width_that_is_not_a_multiple_of_4(hip, tmp_path):
     assert float(pad.abs().max()) == 0.0, 'weights of the padding columns stay zero'
 
 
+def test_end_to_end_training_above_8192_rows_vs_oracle(hip, tmp_path):
+    """One PPO.train() epoch of the product against the oracle's on the deterministic env with minibatches of 16,384 rows: the
+    regime of the per-layer kernels (split-bf16 GEMMs, streamed LayerNorm backward, any-order weight-gradient launches), which
+    the reference's own fixtures (64 envs) do not reach.  DFlexAntPPO network, 1,024 envs x 32 steps, 2 mini-epochs."""
+    from mineral_amd.agents import PPO
+    from test_oracle_golden import run_oracle_training
+    spec = NETS['full']
+    ospec = dict(obs=spec['obs'], act=spec['act'], units=spec['units'], norm='LayerNorm', act_type='SiLU', fixed_sigma=False, dist_type='dreamerv3_normal')
+    N, T, mb, mini_epochs, epochs = 1024, 32, 16384, 2, 1
+    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
+    agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
+    agent.model.load_state_dict(synth.make_params(synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], True, True, False), 5))
+    agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
+    agent.save = lambda *a, **k: None
+    agent._checkpoint_save = lambda *a, **k: None
+    got = {}
+    orig = agent.train_epoch
+
+    def spy():
+        res = orig()
+        for k in ('loss/total', 'loss/actor', 'loss/critic', 'explained_var', 'grad_norm/all', 'kl'):
+            got[k] = cpu(res[k]).clone()
+        return res
+
+    agent.train_epoch = spy
+    agent.train()
+    want = {}
+
+    def on_epoch(e, pre, data, res, lr, obs_rms, value_rms, params):
+        want.update(params={k: v.clone() for k, v in params.items()}, obs_rms=obs_rms, lr=lr, mu=data['mu'].clone(), res=res)
+
+    run_oracle_training(ospec, dict(N=N, T=T, mb=mb, mini_epochs=mini_epochs, epochs=epochs, optim='AdamW'), on_epoch)
+    assert agent.last_lr == want['lr'], 'KL-adaptive learning rate path'
+    rms = agent.obs_rms['obs']
+    assert_close(cpu(rms.running_mean), want['obs_rms']['running_mean'], 1e-6, 2e-7)
+    assert_close(cpu(rms.running_var), want['obs_rms']['running_var'], 1e-5, 2e-7)
+    assert_close(cpu(agent.storage.storage_dict['mu'].view(-1, spec['act'])), want['mu'], rtol=1e-4, atol=2e-5)
+    for k in ('loss/total', 'loss/actor', 'loss/critic', 'explained_var', 'grad_norm/all', 'kl'):
+        assert_close(got[k], torch.tensor(np.array(want['res'][k], dtype=np.float32)), rtol=2e-3, atol=2e-5, what=k)
+    for n, p in agent.model.named_parameters():
+        assert_close(cpu(p), want['params'][n], rtol=2e-3, atol=2e-5, what=n)
+
+
 def test_full_size_properties(hip):
     """BASELINE-size shapes (N=65536 envs, T=32, minibatch 32768) through size-independent properties."""
     from mineral_amd.common.normalizers import RunningMeanStd
@@ -621,17 +665,21 @@ def test_full_size_properties(hip):
 
 
 @pytest.mark.gpu
-def test_two_ranks_share_one_gpu_through_host_staged_gloo():
+@pytest.mark.parametrize('mb', [4096, 16384])
+def test_two_ranks_share_one_gpu_through_host_staged_gloo(mb):
     """The multi-rank agent path (parameter broadcast, sharded GAE statistics, merged observation moments, gradient
     all-reduce, KL all-reduce) run as two processes on this GPU with gloo through host memory: both ranks must end
-    with bit-identical parameters.  RCCL itself needs one GPU per rank and is exercised by the scaling benchmark."""
+    with bit-identical parameters, with the kernels of both minibatch regimes (chain kernels up to 8192 rows, per-layer
+    split-bf16 kernels above).  The ranks step different environments, so there is no single-process run with the same
+    numbers to compare with; that comparison is made with one rank (test_one_rank_rccl_group_matches_the_single_process_path).
+    RCCL itself needs one GPU per rank and is exercised by the scaling benchmark."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--backend', 'gloo',
-           '--num-envs', '1024', '--minibatch', '4096', '--no-kernel-timing']
+           '--num-envs', '1024', '--minibatch', str(mb), '--no-kernel-timing']
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
@@ -826,24 +874,28 @@ def test_torch_custom_operators_run_the_same_kernels(hip):
 
 
 @pytest.mark.gpu
-def test_one_rank_rccl_group_matches_the_single_process_path():
+@pytest.mark.parametrize('mb', [4096, 16384])
+def test_one_rank_rccl_group_matches_the_single_process_path(mb):
     """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
     issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's
-    bit for bit (global statistics of one rank are its local ones)."""
+    bit for bit (global statistics of one rank are its local ones).  The single-process run takes the one-call mini-epoch, the
+    ranked run merge / gradient / all-reduce / optimizer calls per minibatch; 4096 rows run the chain kernels, 16384 the
+    per-layer split-bf16 kernels."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for extra in ([], ['--force-dist']):
-        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '4096',
-               '--no-kernel-timing', '--no-cpu-baseline'] + extra
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', str(mb),
+               '--no-kernel-timing', '--no-cpu-baseline', '--no-secondary'] + extra
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]))
     assert outs[1]['ranks_in_sync'] is True
     assert outs[0]['param_checksum'] == outs[1]['param_checksum']
+    assert outs[0]['param_sha256'] == outs[1]['param_sha256']
 
 
 @pytest.mark.gpu
@@ -967,10 +1019,11 @@ def test_the_one_call_step_and_mini_epoch_equal_the_three_calls(hip, mb, net):
 
 @pytest.mark.gpu
 def test_launch_structures_of_the_update_are_bit_identical():
-    """Above 8192 rows mrl_ppo_grad lets the weight-gradient launches run beside the dgrad launch that reads the same dZ
-    (any-order launches on the caller's stream; MRL_ANY_ORDER=0 keeps every launch in order), or, with MRL_TOWER_STREAMS=1,
-    runs one launch chain per tower plus the weight gradients on library-owned streams (fork / join by events).  Same
-    kernels, same fixed-order reductions: the parameters after two updates must be equal bit for bit in all three."""
+    """On the per-layer path (batches above 8192 rows) mrl_ppo_grad lets the weight-gradient launches run beside the dgrad launch
+    that reads the same dZ (any-order launches on the caller's stream; MRL_ANY_ORDER=0 keeps every launch in order), or, with
+    MRL_TOWER_STREAMS=1, runs one launch chain per tower plus the weight gradients on library-owned streams (fork / join by
+    events).  Same kernels, same fixed-order reductions: every bit of every parameter after two updates (sha256 of the vector)
+    must be the same in all three."""
     import json
     import subprocess
     import sys
@@ -978,10 +1031,10 @@ def test_launch_structures_of_the_update_are_bit_identical():
     sums = []
     for env in (dict(MRL_ANY_ORDER='0', MRL_TOWER_STREAMS='0'), dict(MRL_ANY_ORDER='1', MRL_TOWER_STREAMS='0'), dict(MRL_TOWER_STREAMS='1')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', '16384',
-               '--no-kernel-timing', '--no-cpu-baseline']
+               '--no-kernel-timing', '--no-cpu-baseline', '--no-secondary']
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, **env))
         assert res.returncode == 0, res.stderr[-2000:]
-        sums.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])['param_checksum'])
+        sums.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])['param_sha256'])
     assert sums[0] == sums[1] == sums[2]
 
 

@@ -273,3 +273,54 @@ def test_custom_operators_are_registered_for_the_device_only():
     with pytest.raises(NotImplementedError):
         torch.ops.mineral.clip_adam_step_(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 1e-3, 0.9, 0.999, 1e-8, 0.0, False, 1, 0.0, 1.0,
                                           None, torch.zeros(4096, dtype=torch.uint8))
+
+
+def test_template_agent_subclass_constructs_and_base_helpers(tmp_path):
+    """mineral/agents/template_agent.py: the smallest subclass goes through the base constructor (agent.py:13-81); the base
+    class's helpers `_as_metrics`, `_handle_timeout`, `_convert_obs` and the abstract `get_actions` / `explore_env` behave as
+    agent.py:83-167.  The episode metrics live on the GPU, so this CPU test gives the subclass a stand-in for them (the
+    constructor's call of `_create_metrics` is still exercised) and checks that the real ones refuse a CPU device loudly."""
+    import types
+    import torch
+    from mineral_amd import _hip, agents
+    from mineral_amd.config import Config
+
+    class Space:
+        def __init__(self, shape):
+            self.shape = shape
+
+    env = types.SimpleNamespace(action_space=Space((3,)), observation_space=Space((5,)))
+    cfg = Config.wrap(dict(rl_device='cpu', multi_gpu=False, env_render=False, task={},
+                           agent=dict(algo='Template', network=dict(normalize_input=True, cpu_obs_keys='^img'), template=dict(num_actors=4, max_agent_steps=100),
+                                      print_every=1)))
+    assert agents.Template is getattr(agents, cfg.agent.algo)
+    with pytest.raises(_hip.HipLibraryError):        # the real metrics: device only, no CPU fallback
+        agents.Template(cfg, logdir=str(tmp_path / 'a'), env=env)
+
+    class Mine(agents.Template):
+        def _create_metrics(self, tracker_len, metrics_kwargs):
+            return ('metrics', tracker_len)
+
+    a = Mine(cfg, logdir=str(tmp_path / 'b'), accelerator=None, datasets=None, env=env)
+    assert a.num_actors == 4 and a.max_agent_steps == 100 and a.action_dim == 3 and a.obs_space == {'obs': (5,)}
+    assert a.metrics == ('metrics', 100) and a.normalize_input is True and (a.epoch, a.mini_epoch, a.agent_steps) == (-1, -1, 0)
+    assert os.path.isdir(os.path.join(str(tmp_path / 'b'), 'ckpt'))
+    for call in (lambda: a.get_actions(None), lambda: a.explore_env(None, 1)):
+        with pytest.raises(NotImplementedError):
+            call()
+    assert a.train() is None and a.eval() is None and a.save('x') is None and a.load('x') is None
+    with a._as_metrics('eval metrics'):
+        assert a.metrics == 'eval metrics'
+    assert a.metrics == ('metrics', 100)
+    with pytest.raises(RuntimeError):
+        with a._as_metrics('eval metrics'):
+            raise RuntimeError
+    assert a.metrics == ('metrics', 100)
+    dones = torch.tensor([True, True, False, True])
+    trunc = torch.tensor([False, True, False, False])
+    assert torch.equal(agents.Agent._handle_timeout(dones, {'TimeLimit.truncated': trunc}), torch.tensor([True, False, False, True]))
+    assert torch.equal(agents.Agent._handle_timeout(dones, {'time_outs': ~trunc, 'truncated': trunc}), dones * trunc)   # the first key found decides
+    assert agents.Agent._handle_timeout(dones, {}) is dones
+    o = a._convert_obs({'obs': np.zeros((4, 5), np.float32), 'img0': np.zeros((4, 2), np.float32), 't': torch.ones(4)})
+    assert o['obs'].device.type == 'cpu' and o['img0'].device.type == 'cpu' and o['t'].shape == (4,)
+    assert set(a._convert_obs(np.zeros((4, 5), np.float32))) == {'obs'}

@@ -39,12 +39,37 @@ def _run(N, T, static, seed):
     return out
 
 
+def _assert_allocates_nothing(N, T, seed):
+    """The device's free memory before and after a call of the entry point with every argument prepared beforehand (the first
+    call on a device, which looks up the scratch array's address and may load the code object, has happened: callers that
+    capture graphs make one call outside the capture for the same reason)."""
+    from mineral_amd import _hip
+    from mineral_amd.agents.ppo.experience import ExperienceBuffer
+    from mineral_amd.common.normalizers import RunningMeanStd
+    L = _hip.lib()
+    buf = ExperienceBuffer(N, T, N * T, N * T, {'obs': (8,)}, 2, DEV)
+    s = buf.storage_dict
+    s['rewards'].copy_(synth.gaussianish((T, N, 1), seed))
+    s['values'].copy_(synth.gaussianish((T, N, 1), seed + 1))
+    last = synth.gaussianish((N,), seed + 4).to(DEV)
+    vr = RunningMeanStd((1,), eps=1e-5, with_clamp=True, initial_count=1, device=DEV)
+    stats = torch.zeros(8, device=DEV)
+    c, vc = buf.c, vr.c_struct()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    _hip.check(L.mrl_gae_finish_static(c, _hip.ptr(last), 0.99, 0.95, vc, _hip.ptr(stats), None), 'static')
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, 'the entry point must not allocate device memory'
+
+
 def test_static_scratch_entry_point_matches_the_workspace_one():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     # the larger rollout first, then a smaller one: the scratch still holds the partial sums of the first call
     for N, T, seed in ((70001, 16, 30), (333, 7, 40)):
         got = _run(N, T, True, seed)
+        if seed == 40:
+            _assert_allocates_nothing(N, T, seed)
         ref = _run(N, T, False, seed)
         for k in ref:
             assert torch.equal(got[k], ref[k]), f'{k} differs at N={N}, T={T}'
