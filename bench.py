@@ -92,7 +92,7 @@ def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` at this workload, from the committed rocprofv3 counter passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs by tools/pmc_traffic.sh and cannot be read from inside this process);
     None when no measurement of that kernel is on file."""
-    path = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
     try:
         with open(path) as f:
             return json.load(f)['kernels'][kernel]['hbm_bytes']
@@ -103,8 +103,8 @@ def measured_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--num-envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--minibatch', type=int, default=32768, help='minibatch rows per GPU')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -173,12 +173,20 @@ def main():
         torch.cuda.synchronize()
         L.mrl_profile_enable(2)           # fixes the dominant instantiation from the warm-up's timings ...
         L.mrl_profile_enable(0)           # ... timed region: no events, the product's own launch order
+    calls0 = dict(agent._dist.calls) if multi and hasattr(agent._dist, 'calls') else None
     fence()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         one_step()
+        torch.cuda.synchronize()     # per-update times for the median; the update itself already syncs once per mini-epoch (KL-adaptive lr)
+        step_times.append(time.perf_counter() - ts)
     fence()
     dt = time.perf_counter() - t0
+    collectives_per_update = None
+    if calls0 is not None:
+        collectives_per_update = {k: (v - calls0.get(k, 0)) / args.steps for k, v in agent._dist.calls.items()}
     flat64 = agent.model.flat.double()
     param_checksum = [float(flat64.sum().item()), float((flat64 * flat64).sum().item())]   # run-to-run / rank-count comparisons
     import hashlib
@@ -225,7 +233,7 @@ def main():
         text = C.create_string_buffer(16384)
         n = L.mrl_profile_read_all(text, 16384)
         kernel_table = []
-        for line in text.value.decode().splitlines()[:12] if n > 0 else []:
+        for line in text.value.decode().splitlines() if n > 0 else []:
             ms, launches, flops, kname = line.split('\t')
             ms, launches, flops = float(ms), int(launches), float(flops)
             kernel_table.append({'name': kname, 'launches': launches, 'avg_us': 1e3 * ms / launches, 'total_ms': ms,
@@ -238,7 +246,7 @@ def main():
     out = {
         'metric': f'PPO env-steps/sec, synthetic env (obs=64, act=12), {args.num_envs} envs per MI355X',
         'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': 1e3 * dt / args.steps, 'ms_per_step_median': 1e3 * sorted(step_times)[len(step_times) // 2], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'PPO DFlexAntPPO hparams, {args.num_envs} envs/GPU x T=32, minibatch {args.minibatch}, '
                                f'5 mini-epochs, MLP [512,256,128] LayerNorm+SiLU, AdamW, KL-adaptive lr',
@@ -247,6 +255,8 @@ def main():
                    'num_envs_total': args.num_envs * world, 'ms_per_update': 1e3 * dt / args.steps,
                    'parallelism': f'dp{world} (envs sharded, 1 RCCL all-reduce of the flat gradient per optimizer step)'},
     }
+    if collectives_per_update is not None:
+        out['collectives_per_update'] = collectives_per_update
     out['param_checksum'] = param_checksum
     out['param_sha256'] = param_sha256
     if multi:
@@ -273,8 +283,33 @@ def main():
                                    'frac_of_fp32_mfma_peak': achieved / 157.3,
                                    'measured_over': f'a second pass of the same {args.steps} steps with HIP events around every launch of this kernel '
                                                     f'(every launch in order), {1e3 * dt_events / args.steps:.1f} ms per step'}
+                # the whole update against the same ceiling: algorithmic MACs per env step = the rollout's forward + 5 mini-epochs x
+                # (forward + backward) of both towers and heads, less the first layers' input gradients, which nothing needs
+                w_all = 2 * (64 * 512 + 512 * 256 + 256 * 128) + 128 * 24 + 128 * 1
+                flop_per_env_step = 2.0 * (16 * w_all - 5 * 2 * 64 * 512)
+                upd_tflops = flop_per_env_step * args.num_envs * T_HORIZON / (dt / args.steps) / 1e12
+                out['roofline']['update_tflops'] = upd_tflops
+                out['roofline']['update_frac'] = upd_tflops / peak
                 if kernel_table:
-                    out['roofline']['kernels'] = kernel_table
+                    out['roofline']['kernels'] = kernel_table[:12]
+                    # the streaming kernels of the update: HBM bytes per launch from the committed counter passes over this same
+                    # workload (profiles/r03_traffic.json) over the event time measured here
+                    hbm = []
+                    for row in kernel_table:
+                        nm = row['name'].split(' + ')[0]
+                        if not any(k in nm for k in ('gae_kernel', 'gae_normalize', 'moments_partial', 'rollout_write', 'ln_bwd', 'reduce_slabs', 'reduce_flat',
+                                                     'gradnorm', 'adam')):
+                            continue
+                        by = measured_traffic(nm if 'ln_bwd' in nm else nm.split('<')[0])
+                        if by is None and nm == 'moments_partial_kernel':
+                            by = measured_traffic('moments_partial4_kernel')   # the 16-byte-load variant taken for column counts that are multiples of 4
+                        if 'adam' in row['name'] and by is not None:
+                            by2 = measured_traffic('adam_kernel')
+                            by = by + by2 if by2 is not None else by
+                        hbm.append({'name': row['name'], 'launches': row['launches'], 'avg_us': row['avg_us'], 'hbm_bytes': by,
+                                    'achieved_gbs': (by / (row['avg_us'] * 1e-6) / 1e9) if by else None,
+                                    'frac_of_8tbs': (by / (row['avg_us'] * 1e-6) / 8e12) if by else None})
+                    out['roofline']['hbm_kernels'] = hbm
         if not args.no_secondary and not multi and args.minibatch != 2048:
             # the minibatch size the reference ships for this network (cfgs/agent/DFlexAntPPO.yaml: minibatch_size 2048):
             # 5,120 optimizer steps per update instead of 320, a launch- and latency-bound regime

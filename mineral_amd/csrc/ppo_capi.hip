@@ -1119,23 +1119,37 @@ __global__ __launch_bounds__(64) void gae_kernel(const float* __restrict__ rewar
   if (n < N) {
     float next_v = last_values[n];
     float last = 0.0f;
-    for (int t = T - 1; t >= 0; --t) {
-      int64_t i = (int64_t)t * N + n;
-      float v = values[i];
-      float nnt = 1.0f - (float)dones[i];
+    auto step = [&](int t, float v, float r, float dn, float nl) {
+      float nnt = 1.0f - dn;
       // delta = r + gamma*next_values*nnt - v ; adv = delta + (gamma*tau)*nnt*last   (unfused, as torch evaluates it)
-      float delta = sub_rn(add_rn(rewards[i], mul_rn(mul_rn(gamma, next_v), nnt)), v);
+      float delta = sub_rn(add_rn(r, mul_rn(mul_rn(gamma, next_v), nnt)), v);
       last = add_rn(delta, mul_rn(mul_rn(gamma_tau, nnt), last));
       float ret = add_rn(last, v);
       s_ret[lane * S + t] = ret;
       s_val[lane * S + t] = v;
       float adv = sub_rn(ret, v);      // experience.py:119: advantages = returns - values
       s_adv[lane * S + t] = adv;
-      s_nlp[lane * S + t] = neglogp_tn[i];
+      s_nlp[lane * S + t] = nl;
       sa += adv; sa2 += (double)adv * adv;
       sv += v; sv2 += (double)v * v;
       sr += ret; sr2 += (double)ret * ret;
       next_v = v;
+    };
+    // the recurrence is sequential in t, its operands are not: 8 time steps at a time, their 32 loads in flight together
+    int t = T - 1;
+    for (; t >= 7; t -= 8) {
+      float v8[8], r8[8], d8[8], n8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t i = (int64_t)(t - k) * N + n;
+        v8[k] = values[i]; r8[k] = rewards[i]; d8[k] = (float)dones[i]; n8[k] = neglogp_tn[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) step(t - k, v8[k], r8[k], d8[k], n8[k]);
+    }
+    for (; t >= 0; --t) {
+      const int64_t i = (int64_t)t * N + n;
+      step(t, values[i], rewards[i], (float)dones[i], neglogp_tn[i]);
     }
   }
   double vals[6] = {sa, sa2, sv, sv2, sr, sr2};
@@ -1233,6 +1247,53 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __res
     }
     smd[rl * cols + c] = s;
     smd[(rowlanes + rl) * cols + c] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < cols) {
+    double a = 0, b = 0;
+    for (int i = 0; i < rowlanes; ++i) {
+      a += smd[i * cols + threadIdx.x];
+      b += smd[(rowlanes + i) * cols + threadIdx.x];
+    }
+    double* o = part + ((g * gridDim.x + ch) * 2) * cols;
+    o[threadIdx.x] = a;
+    o[cols + threadIdx.x] = b;
+  }
+}
+
+// The same for column counts that are multiples of 4: a thread takes 4 columns (16-byte loads) and every (256 / (cols / 4))-th row,
+// four rows per pass so that four loads are in flight; fp64 accumulators per column, combined over the thread rows in a fixed order.
+__global__ __launch_bounds__(256) void moments_partial4_kernel(const float* __restrict__ x, int cols, int64_t group_rows,
+                                                               int64_t chunk_rows, double* __restrict__ part) {
+  extern __shared__ double smd[];   // [2][rowlanes][cols]
+  const int c4n = cols >> 2, rowlanes = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const int64_t g = blockIdx.y, ch = blockIdx.x;
+  int64_t r0 = ch * chunk_rows, r1 = r0 + chunk_rows;
+  if (r1 > group_rows) r1 = group_rows;
+  double s[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (rl < rowlanes) {
+    const float* base = x + (g * group_rows) * cols + 4 * c4;
+    int64_t r = r0 + rl;
+    for (; r + 3 * rowlanes < r1; r += 4 * rowlanes) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + u * rowlanes) * cols);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += v[u][e]; s2[e] += (double)v[u][e] * v[u][e]; }
+    }
+    for (; r < r1; r += rowlanes) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + r * cols);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += v[e]; s2[e] += (double)v[e] * v[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      smd[rl * cols + 4 * c4 + e] = s[e];
+      smd[(rowlanes + rl) * cols + 4 * c4 + e] = s2[e];
+    }
   }
   __syncthreads();
   if (threadIdx.x < cols) {
@@ -1399,21 +1460,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
 }
 
 // Sum `nslabs` partial slabs into the flat gradient.  One descriptor per gradient tensor; grid.y = descriptor.
-struct ReduceDesc { const float* src; float* dst; int64_t count; int64_t stride; int nslabs; };
+struct ReduceDesc { const float* src; float* dst; int64_t count; int64_t stride; int nslabs; int block0; };
 #define MRL_MAX_RDESC 48
 struct ReduceTable { ReduceDesc d[MRL_MAX_RDESC]; int n; };
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
+  // blockIdx.x counts the 16-chunk pieces of all descriptors (ReduceDesc::block0 = first piece of a descriptor)
   // block = 16 column chunks (of 4 floats) x 16 slab lanes: lane q sums slabs q, q+16, ... and the 16 partial sums are
   // combined in a fixed order through LDS, so the result does not depend on scheduling.  Many short dependent chains
   // beat long coalesced ones here: 64 chunks x 4 slab lanes measured 49 us against 28 us for this mapping.
   constexpr int CH = 16, QL = 16;
   __shared__ f32x4 red[QL][CH];
-  const ReduceDesc d = tab.d[blockIdx.y];
+  int di = 0;
+  for (int k = 1; k < tab.n; ++k)
+    if ((int)blockIdx.x >= tab.d[k].block0) di = k;
+  const ReduceDesc d = tab.d[di];
+  const int lb = blockIdx.x - d.block0, nb = (di + 1 < tab.n ? tab.d[di + 1].block0 : (int)gridDim.x) - d.block0;
   const int cx = threadIdx.x & (CH - 1), q = threadIdx.x / CH;
   if ((d.count & 3) == 0 && (d.stride & 3) == 0) {
     const int64_t n4 = d.count >> 2;
-    for (int64_t c0 = (int64_t)blockIdx.x * CH; c0 < n4; c0 += (int64_t)gridDim.x * CH) {
+    for (int64_t c0 = (int64_t)lb * CH; c0 < n4; c0 += (int64_t)nb * CH) {
       const int64_t i = c0 + cx;
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
       if (i < n4) {
@@ -1438,7 +1504,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab
       __syncthreads();
     }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < d.count; i += (int64_t)nb * 256) {
       float s = 0.f;
       for (int k = 0; k < d.nslabs; ++k) s += d.src[k * d.stride + i];
       d.dst[i] = s;
@@ -1742,9 +1808,12 @@ extern "C" int mrl_rollout_write(const mrl_rollout* buf, int32_t t, const float*
   if (t < 0 || t >= buf->horizon) MRL_FAIL(MRL_EINVAL, "step %d outside 0..%d", t, buf->horizon - 1);
   if (!rewards || !dones) MRL_FAIL(MRL_EINVAL, "NULL rewards/dones");
   const int64_t N = buf->num_envs;
-  hipLaunchKernelGGL(rollout_write_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
-                     buf->rewards_tn + (int64_t)t * N, buf->dones_tn + (int64_t)t * N, buf->values_tn + (int64_t)t * N, rewards,
-                     dones, time_outs, N, (float)reward_scale, (float)gamma);
+  {
+    MRL_PROF_STREAM("rollout_write_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(rollout_write_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       buf->rewards_tn + (int64_t)t * N, buf->dones_tn + (int64_t)t * N, buf->values_tn + (int64_t)t * N, rewards,
+                       dones, time_outs, N, (float)reward_scale, (float)gamma);
+  }
   MRL_CHECK_LAUNCH("mrl_rollout_write");
   return MRL_OK;
 }
@@ -1764,9 +1833,12 @@ extern "C" int mrl_gae_scan(const mrl_rollout* buf, const float* last_values, do
   hipStream_t s = (hipStream_t)stream;
   double* part = (double*)workspace;
   const float gamma_tau = (float)(gamma * tau);   // the reference multiplies the two Python floats first
-  hipLaunchKernelGGL(gae_kernel, dim3(nblocks), dim3(64), smem, s, buf->rewards_tn, buf->values_tn, buf->dones_tn,
-                     buf->neglogp_tn, last_values, N, T, (float)gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
-                     buf->neglogp, part);
+  {
+    MRL_PROF_STREAM("gae_kernel", s);
+    hipLaunchKernelGGL(gae_kernel, dim3(nblocks), dim3(64), smem, s, buf->rewards_tn, buf->values_tn, buf->dones_tn,
+                       buf->neglogp_tn, last_values, N, T, (float)gamma, gamma_tau, buf->returns, buf->values, buf->advantages,
+                       buf->neglogp, part);
+  }
   hipLaunchKernelGGL(gae_sums_kernel, dim3(1), dim3(256), 0, s, part, nblocks, sums_out);
   MRL_CHECK_LAUNCH("mrl_gae_scan");
   return MRL_OK;
@@ -1782,9 +1854,12 @@ extern "C" int mrl_gae_normalize(const mrl_rollout* buf, const double* sums, dou
                      value_rms ? value_rms->var : nullptr, value_rms ? value_rms->count : nullptr,
                      value_rms ? value_rms->eps : 0.f, stats_out);
   const int64_t B = buf->num_envs * (int64_t)buf->horizon;
-  hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, s, buf->advantages, buf->values,
-                     buf->returns, stats_out, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
-                     value_rms ? value_rms->clamp_hi : 0.f);
+  {
+    MRL_PROF_STREAM("gae_normalize_kernel", s);
+    hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, s, buf->advantages, buf->values,
+                       buf->returns, stats_out, B, value_rms ? 1 : 0, value_rms ? value_rms->clamp_lo : 0.f,
+                       value_rms ? value_rms->clamp_hi : 0.f);
+  }
   MRL_CHECK_LAUNCH("mrl_gae_normalize");
   return MRL_OK;
 }
@@ -1928,10 +2003,16 @@ extern "C" int mrl_batch_moments(const float* x, int64_t rows, int32_t cols, int
   if (workspace_bytes < need) MRL_FAIL(MRL_ENOSPC, "workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
   if (reinterpret_cast<uintptr_t>(workspace) & 255) MRL_FAIL(MRL_EINVAL, "workspace %p is not 256-byte aligned", workspace);
   hipStream_t s = (hipStream_t)stream;
-  const int rowlanes = 256 / cols > 0 ? 256 / cols : 1;
-  size_t smem = (size_t)2 * rowlanes * cols * sizeof(double);
-  hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), smem, s, x, cols, group_rows,
-                     chunk_rows, (double*)workspace);
+  MRL_PROF_STREAM("moments_partial_kernel", s);
+  if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int rowlanes = 256 / (cols / 4);
+    hipLaunchKernelGGL(moments_partial4_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), (size_t)2 * rowlanes * cols * sizeof(double), s, x, cols,
+                       group_rows, chunk_rows, (double*)workspace);
+  } else {
+    const int rowlanes = 256 / cols > 0 ? 256 / cols : 1;
+    hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)chunks, (unsigned)groups), dim3(256), (size_t)2 * rowlanes * cols * sizeof(double), s, x, cols,
+                       group_rows, chunk_rows, (double*)workspace);
+  }
   hipLaunchKernelGGL(moments_final_kernel, dim3((cols + 255) / 256, (unsigned)groups), dim3(256), 0, s, (const double*)workspace,
                      (int)chunks, cols, (double)group_rows, correction, mean_out, var_out);
   MRL_CHECK_LAUNCH("mrl_batch_moments");
@@ -2350,10 +2431,14 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
     if (flat_done) *flat_done = true;
     return;
   }
-  int gx = (int)cdiv(maxcount, 64);
-  if (gx > 2048) gx = 2048;
+  (void)maxcount;
+  int nblocks = 0;   // one block per 16 chunks of 4 floats, at most 2048 per descriptor
+  for (int i = 0; i < tab.n; ++i) {
+    tab.d[i].block0 = nblocks;
+    nblocks += (int)std::min<int64_t>(2048, std::max<int64_t>(1, cdiv(tab.d[i].count, 64)));
+  }
   MRL_PROF_STREAM("reduce_slabs_kernel", s);
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, tab.n), dim3(256), 0, s, tab);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, s, tab);
 }
 
 // A second stream per device for the per-tower launch chains of mrl_ppo_grad (actor on the caller's stream, critic on this

@@ -39,9 +39,41 @@ class HostStaged:
         self._d.barrier()
 
 
+class Counted:
+    """The collectives object handed to the agent, counting what goes through it (`calls`: name -> number of calls, `elements`:
+    name -> tensor elements sent) so that benchmarks can report collectives per update."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.calls, self.elements = {}, {}
+
+    def _note(self, name, t):
+        self.calls[name] = self.calls.get(name, 0) + 1
+        self.elements[name] = self.elements.get(name, 0) + int(t.numel())
+
+    def is_initialized(self):
+        return self._inner.is_initialized()
+
+    def all_reduce(self, t, op=None):
+        self._note('all_reduce', t)
+        return self._inner.all_reduce(t) if op is None else self._inner.all_reduce(t, op=op)
+
+    def all_gather(self, outs, t):
+        self._note('all_gather', t)
+        return self._inner.all_gather(outs, t)
+
+    def broadcast(self, t, src=0):
+        self._note('broadcast', t)
+        return self._inner.broadcast(t, src=src)
+
+    def barrier(self):
+        return self._inner.barrier()
+
+
 def collectives(dist):
-    """The object the agent calls its collectives on: torch.distributed for nccl, the host-staged wrapper for gloo."""
-    return HostStaged(dist) if dist.get_backend() == 'gloo' else dist
+    """The object the agent calls its collectives on: torch.distributed for nccl, the host-staged wrapper for gloo, behind a
+    call counter."""
+    return Counted(HostStaged(dist) if dist.get_backend() == 'gloo' else dist)
 
 
 def combine_moments(mean, var, count, dist, world_size):
