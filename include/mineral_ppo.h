@@ -44,6 +44,14 @@ extern "C" {
 #define MRL_TOWER_LAYERNORM_SILU 0   /* [Linear -> LayerNorm -> SiLU] per layer (DFlexAntPPO.yaml, AllegroHandPPO.yaml) */
 #define MRL_TOWER_ELU 1              /* [Linear -> ELU] per layer, no normalisation (CartpolePPO.yaml) */
 #define MRL_TOWER_LAYERNORM_ELU 2     /* [Linear -> LayerNorm -> ELU] per layer (the mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) */
+/* the other norm_type / act_type combinations of mineral/nets/mlp.py:5-22 (norm None or LayerNorm; SiLU, ELU, ReLU, Tanh); these
+ * five run through the row-local chain kernels at every batch size (the per-layer split-bf16 kernels of large batches are built
+ * for kinds 0-2 only) */
+#define MRL_TOWER_SILU 3             /* [Linear -> SiLU] */
+#define MRL_TOWER_LAYERNORM_RELU 4   /* [Linear -> LayerNorm -> ReLU] */
+#define MRL_TOWER_RELU 5             /* [Linear -> ReLU] (the default act_type of mlp.py) */
+#define MRL_TOWER_LAYERNORM_TANH 6   /* [Linear -> LayerNorm -> Tanh] */
+#define MRL_TOWER_TANH 7             /* [Linear -> Tanh] */
 
 /* ActorCritic description: two towers of n_layers hidden layers, heads mu/sigma (actor) and value (critic).
  * mineral/agents/ppo/models.py:29-73, mineral/nets/mlp.py:25-77, mineral/nets/dist.py:31-47.

@@ -32,11 +32,14 @@ typedef struct mrl_sac_net {
   int32_t critic_units[MRL_MAX_LAYERS];
   float minlogstd, maxlogstd;
   float ln_eps;
+  int32_t actor_kind;    /* MRL_TOWER_* (mineral_ppo.h) of the actor's mlp_kwargs; 0 = LayerNorm + SiLU (DFlexAntSAC.yaml) */
+  int32_t critic_kind;   /* the same for the critics */
 } mrl_sac_net;
 
 /* Flat parameter vectors.  which = 0: the actor (tower, then the [mu; sigma] head of 2*act_dim rows);
  * which = 1: the critic ensemble (tower 0, tower 1, head 0, head 1) — also the layout of the target critics.
- * mrl_sac_param_offsets lists, per tower, per layer W, b, ln_gamma, ln_beta, then per head W, b (float offsets). */
+ * mrl_sac_param_offsets lists, per tower, per layer W, b, ln_gamma, ln_beta (W, b for kinds without a normalisation layer), then
+ * per head W, b (float offsets). */
 int64_t mrl_sac_param_count(const mrl_sac_net* net, int32_t which);
 int mrl_sac_param_offsets(const mrl_sac_net* net, int32_t which, int64_t* offsets, int32_t* n_offsets);
 int64_t mrl_sac_workspace_bytes(const mrl_sac_net* net, int64_t rows);

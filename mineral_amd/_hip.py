@@ -58,15 +58,16 @@ class SacNet(C.Structure):
     """mrl_sac_net (include/mineral_sac.h)."""
     _fields_ = [('obs_dim', C.c_int32), ('act_dim', C.c_int32), ('actor_layers', C.c_int32), ('actor_units', C.c_int32 * MAX_LAYERS),
                 ('critic_layers', C.c_int32), ('critic_units', C.c_int32 * MAX_LAYERS), ('minlogstd', C.c_float), ('maxlogstd', C.c_float),
-                ('ln_eps', C.c_float)]
+                ('ln_eps', C.c_float), ('actor_kind', C.c_int32), ('critic_kind', C.c_int32)]
 
 
-def make_sac_net(obs_dim, act_dim, actor_units, critic_units, minlogstd=-5.0, maxlogstd=2.0, ln_eps=1e-5):
+def make_sac_net(obs_dim, act_dim, actor_units, critic_units, minlogstd=-5.0, maxlogstd=2.0, ln_eps=1e-5, actor_kind=0, critic_kind=0):
+    """actor_kind / critic_kind: MRL_TOWER_* (TOWER_KINDS[(norm_type, act_type)]) of the two mlp_kwargs."""
     if len(actor_units) > MAX_LAYERS or len(critic_units) > MAX_LAYERS:
         raise NotImplementedError(f'at most {MAX_LAYERS} layers per tower')
     au = (C.c_int32 * MAX_LAYERS)(*actor_units)
     cu = (C.c_int32 * MAX_LAYERS)(*critic_units)
-    return SacNet(obs_dim, act_dim, len(actor_units), au, len(critic_units), cu, minlogstd, maxlogstd, ln_eps)
+    return SacNet(obs_dim, act_dim, len(actor_units), au, len(critic_units), cu, minlogstd, maxlogstd, ln_eps, int(actor_kind), int(critic_kind))
 
 
 class CriticNet(C.Structure):
@@ -199,7 +200,9 @@ def require_current_device(device):
     return index
 
 
-TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1, ('LayerNorm', 'ELU'): 2}   # (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
+# (norm_type, act_type) of mineral/nets/mlp.py -> MRL_TOWER_*
+TOWER_KINDS = {('LayerNorm', 'SiLU'): 0, (None, 'ELU'): 1, ('LayerNorm', 'ELU'): 2, (None, 'SiLU'): 3, ('LayerNorm', 'ReLU'): 4, (None, 'ReLU'): 5,
+               ('LayerNorm', 'Tanh'): 6, (None, 'Tanh'): 7}
 
 
 def make_net(obs_dim, act_dim, units, dist_type, minstd=1.0, maxstd=1.0, ln_eps=1e-5, tower_kind=0, fixed_sigma=False):

@@ -28,7 +28,7 @@ class ActorCritic:
             unsupported.append('critic_mlp_kwargs')
         kind = (mlp_kwargs.get('norm_type', None), mlp_kwargs.get('act_type', 'ReLU'))
         if kind not in _hip.TOWER_KINDS:
-            unsupported.append(f'norm_type={kind[0]} with act_type={kind[1]} (built: LayerNorm+SiLU, LayerNorm+ELU, no norm+ELU)')
+            unsupported.append(f'norm_type={kind[0]} with act_type={kind[1]} (built: no norm or LayerNorm with SiLU, ELU, ReLU or Tanh)')
         if mlp_kwargs.get('dropout', None) is not None or mlp_kwargs.get('plain_last', False) or mlp_kwargs.get('out_dim', None):
             unsupported.append('dropout / plain_last / out_dim')
         if dist.get('dist_type', 'normal') not in _hip.DIST_TYPES:
@@ -221,6 +221,6 @@ class ActorCritic:
         return self
 
     def __repr__(self):
-        tower = f'LayerNorm+{self.act_type}' if self.norm_type else 'ELU'
+        tower = f'LayerNorm+{self.act_type}' if self.norm_type else self.act_type
         return (f'ActorCritic[HIP gfx950](obs={self.obs_dim}, act={self.action_dim}, units={self.units}, {tower}, '
                 f'dist={self.dist_type}{", fixed sigma" if self.fixed_sigma else ""}, params={self.param_count})')

@@ -11,17 +11,36 @@ import torch
 from ... import _hip
 
 
-def _mlp_kwargs_ok(kw, what, acts=('SiLU',)):
+def tower_kind_of(kw, what):
+    """MRL_TOWER_* of an mlp_kwargs dict (norm_type None or LayerNorm; act_type SiLU, ELU, ReLU or Tanh; mineral/nets/mlp.py:5-22)."""
+    kind = (kw.get('norm_type', None), kw.get('act_type', 'ReLU'))
     bad = []
-    if kw.get('norm_type', None) != 'LayerNorm':
-        bad.append(f"norm_type={kw.get('norm_type', None)}")
-    if kw.get('act_type', 'ReLU') not in acts:
-        bad.append(f"act_type={kw.get('act_type', 'ReLU')}")
+    if kind not in _hip.TOWER_KINDS:
+        bad.append(f'norm_type={kind[0]} with act_type={kind[1]}')
     if kw.get('dropout', None) is not None:
         bad.append('dropout')
     if bad:
-        raise NotImplementedError(f"{what}: the MI355X kernels cover LayerNorm+{'/'.join(acts)} towers; unsupported here: " + ', '.join(bad))
-    return [int(u) for u in kw.get('units', [512, 256, 128])]
+        raise NotImplementedError(f'{what}: the MI355X kernels cover towers without a norm layer or with LayerNorm, with SiLU, ELU, ReLU or Tanh; '
+                                  'unsupported here: ' + ', '.join(bad))
+    return _hip.TOWER_KINDS[kind]
+
+
+def _mlp_kwargs_ok(kw, what, acts=None):
+    """units (and whether the towers have a norm layer) of an mlp_kwargs dict.  acts: callers whose kernels only take LayerNorm
+    towers with one of these activations (the SHAC critics) get the units alone."""
+    if acts is not None:
+        bad = []
+        if kw.get('norm_type', None) != 'LayerNorm':
+            bad.append(f"norm_type={kw.get('norm_type', None)}")
+        if kw.get('act_type', 'ReLU') not in acts:
+            bad.append(f"act_type={kw.get('act_type', 'ReLU')}")
+        if kw.get('dropout', None) is not None:
+            bad.append('dropout')
+        if bad:
+            raise NotImplementedError(f"{what}: the MI355X kernels cover LayerNorm+{'/'.join(acts)} towers; unsupported here: " + ', '.join(bad))
+        return [int(u) for u in kw.get('units', [512, 256, 128])]
+    tower_kind_of(kw, what)
+    return [int(u) for u in kw.get('units', [512, 256, 128])], kw.get('norm_type', None) is not None
 
 
 class _Flat:
@@ -110,12 +129,14 @@ class _Flat:
         return self
 
 
-def _tower_parts(prefix, in_dim, units):
-    parts, in_f = [], in_dim
+def _tower_parts(prefix, in_dim, units, has_norm=True):
+    """Module indices as nn.Sequential numbers them in mineral/nets/mlp.py:50-77: Linear, (norm,) activation per layer."""
+    parts, in_f, stride = [], in_dim, 3 if has_norm else 2
     for i, u in enumerate(units):
-        b = 3 * i
-        parts += [[(f'{prefix}.mlp.{b}.weight', (u, in_f))], [(f'{prefix}.mlp.{b}.bias', (u,))], [(f'{prefix}.mlp.{b + 1}.weight', (u,))],
-                  [(f'{prefix}.mlp.{b + 1}.bias', (u,))]]
+        b = stride * i
+        parts += [[(f'{prefix}.mlp.{b}.weight', (u, in_f))], [(f'{prefix}.mlp.{b}.bias', (u,))]]
+        if has_norm:
+            parts += [[(f'{prefix}.mlp.{b + 1}.weight', (u,))], [(f'{prefix}.mlp.{b + 1}.bias', (u,))]]
         in_f = u
     return parts
 
@@ -124,12 +145,13 @@ class Actor(_Flat):
     """ddpg/models.py:8-69 with tanh_policy=False, fixed_sigma=False and a squashed_normal Dist."""
 
     def __init__(self, net, state_dim, action_dim, tanh_policy=True, fixed_sigma=None, mlp_kwargs=None, dist_kwargs=None, weight_init=None, device='cuda'):
-        units = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'Actor')
+        units, has_norm = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'Actor')
+        self.kind_name = f"{'LayerNorm+' if has_norm else ''}{dict(mlp_kwargs or {}).get('act_type', 'ReLU')}"
         dist = dict(dist_kwargs or {})
         if tanh_policy or fixed_sigma is not False or dist.get('dist_type') != 'squashed_normal' or weight_init != 'orthogonal':
             raise NotImplementedError('the HIP SAC actor is tanh_policy=False, fixed_sigma=False, dist_type=squashed_normal, weight_init=orthogonal')
         U = units[-1]
-        parts = _tower_parts('actor_mlp', state_dim, units)
+        parts = _tower_parts('actor_mlp', state_dim, units, has_norm)
         parts += [[('mu.weight', (action_dim, U)), ('sigma.weight', (action_dim, U))], [('mu.bias', (action_dim,)), ('sigma.bias', (action_dim,))]]
         super().__init__(net, 0, parts, device)
         self.units = units
@@ -141,20 +163,21 @@ class Actor(_Flat):
         return OrderedDict((k, self._views[k]) for k in keys)
 
     def __repr__(self):
-        return f'Actor[HIP gfx950](units={self.units}, LayerNorm+SiLU, squashed_normal, params={self.param_count})'
+        return f'Actor[HIP gfx950](units={self.units}, {self.kind_name}, squashed_normal, params={self.param_count})'
 
 
 class EnsembleQ(_Flat):
     """ddpg/models.py:72-118 with n_critics=2: every critic an MLP on cat(state, action) ending in a plain Linear to 1."""
 
     def __init__(self, net, state_dim, action_dim, n_critics=2, mlp_kwargs=None, weight_init=None, device='cuda'):
-        units = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'EnsembleQ')
+        units, has_norm = _mlp_kwargs_ok(dict(mlp_kwargs or {}), 'EnsembleQ')
+        self.kind_name = f"{'LayerNorm+' if has_norm else ''}{dict(mlp_kwargs or {}).get('act_type', 'ReLU')}"
         if n_critics != 2 or weight_init != 'orthogonal':
             raise NotImplementedError('the HIP SAC critic ensemble has n_critics=2 and weight_init=orthogonal')
         parts = []
         for c in range(2):
-            parts += _tower_parts(f'critics.{c}', state_dim + action_dim, units)
-        b = 3 * len(units)
+            parts += _tower_parts(f'critics.{c}', state_dim + action_dim, units, has_norm)
+        b = (3 if has_norm else 2) * len(units)
         for c in range(2):
             parts += [[(f'critics.{c}.mlp.{b}.weight', (1, units[-1]))], [(f'critics.{c}.mlp.{b}.bias', (1,))]]
         super().__init__(net, 1, parts, device)
@@ -175,4 +198,4 @@ class EnsembleQ(_Flat):
         return other
 
     def __repr__(self):
-        return f'EnsembleQ[HIP gfx950](n_critics=2, units={self.units}, LayerNorm+SiLU, params={self.param_count})'
+        return f'EnsembleQ[HIP gfx950](n_critics=2, units={self.units}, {self.kind_name}, params={self.param_count})'

@@ -101,7 +101,9 @@ class SAC(Agent):
         minls, maxls = dist.get('minlogstd', None), dist.get('maxlogstd', None)
         if minls is None or maxls is None:
             raise NotImplementedError('squashed_normal needs minlogstd and maxlogstd on the device SAC path')
-        self.net = _hip.make_sac_net(O, A, a_units, c_units, float(minls), float(maxls))
+        self.net = _hip.make_sac_net(O, A, a_units, c_units, float(minls), float(maxls),
+                                     actor_kind=models.tower_kind_of(dict(akw.get('mlp_kwargs', {})), 'Actor'),
+                                     critic_kind=models.tower_kind_of(dict(ckw.get('mlp_kwargs', {})), 'EnsembleQ'))
         self.obs_dim = O
         self.actor = models.Actor(self.net, O, A, device=dev, **akw)
         self.critic = models.EnsembleQ(self.net, O, A, device=dev, **ckw)

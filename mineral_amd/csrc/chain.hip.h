@@ -63,7 +63,14 @@ constexpr int CH_RS = 68;       // floats per row of the row-statistics exchange
 constexpr int CH_RED = CH_ROWS * CH_RS;   // floats of that exchange at the start of the dynamic LDS
 
 // tower kinds, as MRL_TOWER_* of include/mineral_ppo.h
-enum { CH_LN_SILU = 0, CH_PLAIN_ELU = 1, CH_LN_ELU = 2 };
+enum { CH_LN_SILU = 0, CH_PLAIN_ELU = 1, CH_LN_ELU = 2, CH_PLAIN_SILU = 3, CH_LN_RELU = 4, CH_PLAIN_RELU = 5, CH_LN_TANH = 6, CH_PLAIN_TANH = 7, CH_NKINDS = 8 };
+enum { CH_ACT_SILU = 0, CH_ACT_ELU = 1, CH_ACT_RELU = 2, CH_ACT_TANH = 3 };
+constexpr bool ch_kind_norm(int kind) { return kind == CH_LN_SILU || kind == CH_LN_ELU || kind == CH_LN_RELU || kind == CH_LN_TANH; }
+constexpr int ch_kind_act(int kind) {
+  return (kind == CH_LN_SILU || kind == CH_PLAIN_SILU) ? CH_ACT_SILU
+       : (kind == CH_LN_ELU || kind == CH_PLAIN_ELU) ? CH_ACT_ELU
+       : (kind == CH_LN_RELU || kind == CH_PLAIN_RELU) ? CH_ACT_RELU : CH_ACT_TANH;
+}
 
 struct ChainFwdP {
   const float* x;              // [M][in_dim] rows of the first layer's input, row stride in_dim
@@ -108,15 +115,24 @@ struct ChainBwdP {
 // reads (lane = row + 16 * k-group, one 16-byte chunk each) then touch 16 different 4-bank slots per ds_read_b128 lane group.
 __device__ __forceinline__ int ch_off(int row, int chunk, int ld) { return row * ld + ((chunk ^ (row & 15)) << 2); }
 
-template <bool ELU>
+// the activations of mineral/nets/mlp.py:5-22 and their derivatives at the pre-activation y
+template <int ACT>
 __device__ __forceinline__ float ch_act(float y) {
-  if constexpr (ELU) return y > 0.f ? y : __builtin_amdgcn_exp2f(1.44269504088896340736f * y) - 1.0f;
-  else return y * sigmoid_fast(y);
+  if constexpr (ACT == CH_ACT_ELU) return y > 0.f ? y : __builtin_amdgcn_exp2f(1.44269504088896340736f * y) - 1.0f;
+  else if constexpr (ACT == CH_ACT_RELU) return fmaxf(y, 0.f);
+  else if constexpr (ACT == CH_ACT_TANH) {   // 1 - 2 / (1 + e^{2|y|}), sign restored
+    const float e = __builtin_amdgcn_exp2f(2.88539008177792681472f * fabsf(y));
+    return copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e), y);
+  } else return y * sigmoid_fast(y);
 }
-template <bool ELU>
+template <int ACT>
 __device__ __forceinline__ float ch_dact(float y) {
-  if constexpr (ELU) return y > 0.f ? 1.0f : __builtin_amdgcn_exp2f(1.44269504088896340736f * y);
-  else {
+  if constexpr (ACT == CH_ACT_ELU) return y > 0.f ? 1.0f : __builtin_amdgcn_exp2f(1.44269504088896340736f * y);
+  else if constexpr (ACT == CH_ACT_RELU) return y > 0.f ? 1.0f : 0.0f;
+  else if constexpr (ACT == CH_ACT_TANH) {
+    const float th = ch_act<CH_ACT_TANH>(y);
+    return 1.0f - th * th;
+  } else {
     const float sg = sigmoid_fast(y);
     return sg * (1.0f + y * (1.0f - sg));
   }
@@ -205,7 +221,8 @@ __device__ __forceinline__ void chain_fwd_layer(const ChainFwdP& p, int tw, int 
   constexpr int TPW = NTILE >= CH_WAVES ? NTILE / CH_WAVES : 1;     // 16-feature tiles per wave
   constexpr int NACT = NTILE >= CH_WAVES ? CH_WAVES : NTILE;        // waves that own tiles
   constexpr int U = 4 / TPW;                                        // 32-k steps per register group
-  constexpr bool ELU = KIND != CH_LN_SILU, HAS_NORM = KIND != CH_PLAIN_ELU;
+  constexpr bool HAS_NORM = ch_kind_norm(KIND);
+  constexpr int ACT = ch_kind_act(KIND);
   // the lane's indices are rebuilt here, behind an opaque copy of the thread id: hoisted to kernel entry, the address arithmetic of
   // all five layer widths would be live through the whole kernel and spill
   int tid = threadIdx.x;
@@ -338,13 +355,13 @@ __device__ __forceinline__ void chain_fwd_layer(const ChainFwdP& p, int tw, int 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[e] = (z[i][e] - mean) * rstd;
-          h[e] = ch_act<ELU>(xh[e] * g4[i][e] + be4[i][e]);
+          h[e] = ch_act<ACT>(xh[e] * g4[i][e] + be4[i][e]);
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[e] = z[i][e];
-          h[e] = ch_act<true>(xh[e]);
+          h[e] = ch_act<ACT>(xh[e]);
         }
       }
       *reinterpret_cast<f32x4*>(xin + ch_off(r16, c >> 2, ld)) = xh;
@@ -481,7 +498,8 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
   static_assert(N / GW <= CH_WAVES, "one feature group per wave");
   constexpr int U = 8 / J;                                          // 16-k steps per register group
   constexpr int V = 4 * J;                                          // features per lane
-  constexpr bool ELU = KIND != CH_LN_SILU, HAS_NORM = KIND != CH_PLAIN_ELU;
+  constexpr bool HAS_NORM = ch_kind_norm(KIND);
+  constexpr int ACT = ch_kind_act(KIND);
   int tid = threadIdx.x;   // opaque copy: see chain_fwd_layer
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
@@ -558,14 +576,14 @@ __device__ __forceinline__ void chain_bwd_layer(const ChainBwdP& p, int tw, int 
         const float dh = acc[e % J][e / J];
         const float x = x4[q][t];
         if constexpr (HAS_NORM) {
-          const float dy = dh * ch_dact<ELU>(x * g4[q][t] + be4[q][t]);
+          const float dy = dh * ch_dact<ACT>(x * g4[q][t] + be4[q][t]);
           xh[e] = x;
           dyv[e] = dy;
           dxh[e] = dy * g4[q][t];
           s1 += dxh[e];
           s2 += dxh[e] * x;
         } else {
-          dxh[e] = dh * ch_dact<true>(x);                      // plain towers: dZ = dH * elu'(z)
+          dxh[e] = dh * ch_dact<ACT>(x);                       // plain towers: dZ = dH * act'(z)
         }
       }
     if constexpr (HAS_NORM) {
@@ -1052,11 +1070,11 @@ __device__ __forceinline__ void wgrad_small_task(const WgradSmallP& p, const WgD
       return o;
     } else if constexpr (PRO == PRO_ELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = ch_act<true>(v[e]);
+      for (int e = 0; e < 4; ++e) o[e] = ch_act<CH_ACT_ELU>(v[e]);
       return o;
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = ch_act<PRO == PRO_LNELU>(v[e] * pv0[e] + pv1[e]);
+      for (int e = 0; e < 4; ++e) o[e] = ch_act<PRO == PRO_LNELU ? CH_ACT_ELU : CH_ACT_SILU>(v[e] * pv0[e] + pv1[e]);
       return o;
     }
   };
@@ -1394,25 +1412,22 @@ __device__ __forceinline__ void wgrad_tile_task(const WgTileP& p, const WgTileDe
   }
 }
 
-__global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileP p) {
-  extern __shared__ __attribute__((aligned(16))) float wt_lds[];
-  WG_BLOCK(0);
-  // blocks are handed to the 8 XCDs in turn: remapped so that every XCD works on one contiguous eighth of the task list (the
-  // tiles of one row range read the same rows)
-  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-  const int task = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  if (task >= p.ntasks) {
-    int ci = 0;
-    for (int q = 1; q < p.ncd; ++q)
-      if (task >= p.cd[q].task0) ci = q;
-    const WgColDesc& cdsc = p.cd[ci];
-    const int idx = (task - cdsc.task0) * 512 + threadIdx.x;
+// the tasks behind the tiles: sums of the backward chain's per-block column sums (WgColDesc); a block of 512 threads takes
+// 1,024 (chunk, group) outputs, two per thread
+__device__ __forceinline__ void wgrad_col_task(const WgTileP& p, int task) {
+  int ci = 0;
+  for (int q = 1; q < p.ncd; ++q)
+    if (task >= p.cd[q].task0) ci = q;
+  const WgColDesc& cdsc = p.cd[ci];
+  const int per = (cdsc.nblk + cdsc.groups - 1) / cdsc.groups;
+  const int64_t stride = 4 * (int64_t)cdsc.n4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = (task - cdsc.task0) * 1024 + h * 512 + threadIdx.x;
     const int grp = idx / cdsc.n4, ch = idx - grp * cdsc.n4;
-    if (grp >= cdsc.groups) return;
-    const int per = (cdsc.nblk + cdsc.groups - 1) / cdsc.groups;
+    if (grp >= cdsc.groups) continue;
     const int b0 = grp * per, b1 = min(cdsc.nblk, b0 + per);
     const float* src = cdsc.src + 4 * (int64_t)ch;
-    const int64_t stride = 4 * (int64_t)cdsc.n4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int b = b0;
     for (; b + 16 <= b1; b += 16) {
@@ -1424,6 +1439,18 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileP p) {
     }
     for (; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(src + b * stride);
     *reinterpret_cast<f32x4*>(cdsc.dst + grp * stride + 4 * ch) = s;
+  }
+}
+
+__global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileP p) {
+  extern __shared__ __attribute__((aligned(16))) float wt_lds[];
+  WG_BLOCK(0);
+  // blocks are handed to the 8 XCDs in turn: remapped so that every XCD works on one contiguous eighth of the task list (the
+  // tiles of one row range read the same rows)
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int task = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  if (task >= p.ntasks) {
+    wgrad_col_task(p, task);
     return;
   }
   int di = 0;

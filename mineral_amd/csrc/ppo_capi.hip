@@ -60,6 +60,7 @@ struct ParamLayout {
   bool has_norm;          // LayerNorm gain / bias per layer (absent in the plain ELU towers)
 };
 
+static int chain_mask();
 static int check_net(const mrl_net* net) {
   if (!net) MRL_FAIL(MRL_EINVAL, "net is NULL");
   if (net->n_layers < 1 || net->n_layers > MRL_MAX_LAYERS) MRL_FAIL(MRL_EINVAL, "n_layers %d not in 1..%d", net->n_layers, MRL_MAX_LAYERS);
@@ -70,7 +71,9 @@ static int check_net(const mrl_net* net) {
     if (!(u == 32 || u == 64 || u == 128 || u == 256 || u == 512)) MRL_FAIL(MRL_EINVAL, "units[%d]=%d must be 32/64/128/256/512", l, u);
   }
   if (net->dist_type != MRL_DIST_NORMAL && net->dist_type != MRL_DIST_DREAMERV3_NORMAL) MRL_FAIL(MRL_EINVAL, "dist_type %d unsupported", net->dist_type);
-  if (net->tower_kind != MRL_TOWER_LAYERNORM_SILU && net->tower_kind != MRL_TOWER_ELU && net->tower_kind != MRL_TOWER_LAYERNORM_ELU) MRL_FAIL(MRL_EINVAL, "tower_kind %d unsupported", net->tower_kind);
+  if (net->tower_kind < 0 || net->tower_kind >= CH_NKINDS) MRL_FAIL(MRL_EINVAL, "tower_kind %d unsupported", net->tower_kind);
+  if (net->tower_kind > MRL_TOWER_LAYERNORM_ELU && ((chain_mask() & 7) != 7 || net->obs_dim > 512))
+    MRL_FAIL(MRL_EINVAL, "tower_kind %d runs through the chain kernels only (MRL_CHAIN bits 1, 2, 4; at most 512 observation columns)", net->tower_kind);
   if (net->fixed_sigma != 0 && net->fixed_sigma != 1) MRL_FAIL(MRL_EINVAL, "fixed_sigma %d not in {0, 1}", net->fixed_sigma);
   return MRL_OK;
 }
@@ -115,7 +118,7 @@ static void param_layout(const mrl_net* net, ParamLayout* L) {
   const int A = net->act_dim;
   const int hr[2] = {net->fixed_sigma ? A : 2 * A, 1};
   const int hb[2] = {2 * A, 1};
-  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L, net->tower_kind != MRL_TOWER_ELU, hb);
+  param_layout_ex(net->obs_dim, net->n_layers, net->units, 2, hr, L, ch_kind_norm(net->tower_kind), hb);
 }
 
 extern "C" int64_t mrl_param_count(const mrl_net* net) {
@@ -165,7 +168,9 @@ static int chain_mask() {
 // MRL_CHAIN bit 8: the chain kernels read the weights from the parameter tensors as they are (no re-blocked copies, no launch that makes them)
 static bool chain_natural() { return (chain_mask() & 8) != 0; }
 static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
-  return (chain_mask() & bit) != 0 && rows <= MRL_SMALL_M && net->n_layers <= CH_MAXL && net->obs_dim <= 512;   // LDS tiles of at most 512 columns
+  // (tower kinds above MRL_TOWER_LAYERNORM_ELU have no other kernels: any row count)
+  return (chain_mask() & bit) == bit && (rows <= MRL_SMALL_M || net->tower_kind > MRL_TOWER_LAYERNORM_ELU) && net->n_layers <= CH_MAXL &&
+         net->obs_dim <= 512;   // LDS tiles of at most 512 columns
 }
 // 64 x 64 weight-gradient tiles of one tower (layers + head) and the row ranges they are split into: about 1,024 wave tasks
 // for two towers (one per SIMD: the launch keeps one block of four waves per CU), at least 64 rows each, whole multiples of 32 rows
@@ -206,13 +211,14 @@ static ChainWgPlan chain_wgrad_plan(const mrl_net* net, const int* in_dim, int64
     const int u = l == nl ? 32 : net->units[l], in = l == nl ? net->units[nl - 1] : in_dim[l];
     pl.bm[l] = (u <= 32 && in > 64 && !pl.split_bf16) ? 32 : 128;
     pl.bn[l] = in <= 64 ? 64 : 128;
-    cost[l] = pl.bm[l] == 32 ? 1 : (pl.bn[l] == 64 ? 2 : 4);
+    // (the split-bf16 kernel's step is bound by the operand split and the barrier, not by its MFMAs: every tile shape costs the same)
+    cost[l] = pl.split_bf16 ? 4 : (pl.bm[l] == 32 ? 1 : (pl.bn[l] == 64 ? 2 : 4));
     tiles[l] = (int)(cdiv(u, pl.bm[l]) * cdiv(in, pl.bn[l]));
   }
   const int maxs = (int)std::max<int64_t>(1, cdiv(rows, 32) / 2);   // at least 64 rows per range
   // the launch also carries the blocks that sum the backward chain's column sums (WgColDesc): everything in one wave of blocks
   int col_blocks = 0;
-  for (int l = 0; l < nl; ++l) col_blocks += 2 * (int)cdiv((int64_t)(3 * net->units[l] / 4) * std::min<int64_t>(8, cdiv(rows, CH_ROWS)), 512);
+  for (int l = 0; l < nl; ++l) col_blocks += 2 * (int)cdiv((int64_t)(3 * net->units[l] / 4) * std::min<int64_t>(8, cdiv(rows, CH_ROWS)), 1024);
   auto splits_of = [&](int l, int sp) { return std::max(1, (sp * cost[l] + 3) / 4); };
   int best = 1;
   for (int sp = 1; sp <= maxs; ++sp) {
@@ -319,7 +325,7 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
   w->norm_part = o; o = align64(o + 1024);
   w->wplane_stride = align64(L.total);
   w->wplanes = o; o = align64(o + (6 * w->wplane_stride + 1) / 2);   // natural order, then k-blocked order
-  if (chain_ok(net, rows, 3)) {
+  if (chain_ok(net, rows, 1) || chain_ok(net, rows, 2)) {
     for (int tw = 0; tw < 2; ++tw)
       for (int l = 0; l < net->n_layers; ++l) {
         const int u = net->units[l], kn = (l + 1 < net->n_layers) ? net->units[l + 1] : 32;
@@ -723,6 +729,26 @@ static void launch_lnfwd_split(int u, const GemmP& p, int towers, hipStream_t s)
 
 // Forward of the towers on `rows` samples: fills xhat/rstd of every layer.  tw0/towers select the towers.
 // LDS row stride of the chain kernels: every layer width and the (32-padded) input width, rounded up to 64 floats
+// one instantiation of a chain kernel per tower kind (MRL_TOWER_* = the CH_* kinds of chain.hip.h)
+#define MRL_CHAIN_LAUNCH(KERNEL, kind, grid, lds, stream, arg)                                                      \
+  do {                                                                                                              \
+    switch (kind) {                                                                                                 \
+      case CH_PLAIN_ELU: hipLaunchKernelGGL(KERNEL<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break;   \
+      case CH_LN_ELU: hipLaunchKernelGGL(KERNEL<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break;         \
+      case CH_PLAIN_SILU: hipLaunchKernelGGL(KERNEL<CH_PLAIN_SILU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break; \
+      case CH_LN_RELU: hipLaunchKernelGGL(KERNEL<CH_LN_RELU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break;       \
+      case CH_PLAIN_RELU: hipLaunchKernelGGL(KERNEL<CH_PLAIN_RELU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break; \
+      case CH_LN_TANH: hipLaunchKernelGGL(KERNEL<CH_LN_TANH>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break;       \
+      case CH_PLAIN_TANH: hipLaunchKernelGGL(KERNEL<CH_PLAIN_TANH>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break; \
+      default: hipLaunchKernelGGL(KERNEL<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, stream, arg); break;               \
+    }                                                                                                               \
+  } while (0)
+template <int KIND>
+static void chain_allow_lds_kind() {
+  const void* fns[] = {reinterpret_cast<const void*>(chain_fwd_kernel<KIND>), reinterpret_cast<const void*>(chain_bwd_kernel<KIND>),
+                       reinterpret_cast<const void*>(ppo_chain_kernel<KIND>)};
+  for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 static int chain_ld(const mrl_net* net, int in_dim) {
   int m = (in_dim + 31) & ~31;
   for (int l = 0; l < net->n_layers; ++l) m = std::max(m, (int)net->units[l]);
@@ -734,11 +760,9 @@ static size_t chain_bwd_extra_lds(int ld) { return (size_t)(CH_ROWS * ld + CH_CO
 // the widest networks need a little more dynamic LDS than the 64 KB a kernel may ask for by default
 static void chain_allow_lds() {
   static const bool once = [] {
-    const void* fns[] = {reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(chain_fwd_kernel<CH_PLAIN_ELU>),
-                         reinterpret_cast<const void*>(chain_fwd_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_SILU>),
-                         reinterpret_cast<const void*>(chain_bwd_kernel<CH_PLAIN_ELU>), reinterpret_cast<const void*>(chain_bwd_kernel<CH_LN_ELU>),
-                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_SILU>), reinterpret_cast<const void*>(ppo_chain_kernel<CH_PLAIN_ELU>),
-                         reinterpret_cast<const void*>(ppo_chain_kernel<CH_LN_ELU>), reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel),
+    chain_allow_lds_kind<CH_LN_SILU>(); chain_allow_lds_kind<CH_PLAIN_ELU>(); chain_allow_lds_kind<CH_LN_ELU>(); chain_allow_lds_kind<CH_PLAIN_SILU>();
+    chain_allow_lds_kind<CH_LN_RELU>(); chain_allow_lds_kind<CH_PLAIN_RELU>(); chain_allow_lds_kind<CH_LN_TANH>(); chain_allow_lds_kind<CH_PLAIN_TANH>();
+    const void* fns[] = {reinterpret_cast<const void*>(wgrad_small_kernel), reinterpret_cast<const void*>(wgrad_tile_kernel),
                          reinterpret_cast<const void*>(wgrad_group_kernel)};
     for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
@@ -831,9 +855,7 @@ static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Wor
   MRL_PROF_STREAM("mrl::chain_fwd_kernel", s);
   const dim3 grid((unsigned)(p.rows_written / CH_ROWS), towers);
   const size_t lds = chain_lds_bytes(p.ld);
-  if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(chain_fwd_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-  else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_fwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-  else hipLaunchKernelGGL(chain_fwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+  MRL_CHAIN_LAUNCH(chain_fwd_kernel, net->tower_kind, grid, lds, s, p);
 }
 
 static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
@@ -1764,7 +1786,8 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     hipLaunchKernelGGL(rms_to_f32_kernel, dim3((O + 63) / 64), dim3(64), 0, s, obs_rms->mean, obs_rms->var, obs_rms->eps, O, mean_f, std_f);
   }
   const int tw0 = boot ? 1 : 0, towers = boot ? 1 : 2;
-  const unsigned short* wpl = (L.has_norm && N > MRL_SMALL_M) ? launch_split_params(L, W, ws, params, s) : nullptr;
+  const bool hact_ready = net->tower_kind > MRL_TOWER_LAYERNORM_ELU;   // these kinds read the activated output the chain kernel stored
+  const unsigned short* wpl = (L.has_norm && N > MRL_SMALL_M && !chain_ok(net, N, 1)) ? launch_split_params(L, W, ws, params, s) : nullptr;
   launch_towers_fwd(net, L, W, ws, params, obs, N, mean_f, std_f, lo, hi, tw0, towers, s, wpl);
 
   GemmP p;
@@ -1772,7 +1795,7 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
   const int last = net->n_layers - 1, U = net->units[last];
   for (int k = 0; k < towers; ++k) {
     int tw = tw0 + k;
-    p.A[k] = ws + W.xhat[tw][last];
+    p.A[k] = hact_ready ? ws + W.hact[tw][last] : ws + W.xhat[tw][last];
     p.B[k] = params + L.Wh[tw];
     p.pro0[k] = L.has_norm ? params + L.g[tw][last] : nullptr;
     p.pro1[k] = L.has_norm ? params + L.be[tw][last] : nullptr;
@@ -1795,7 +1818,8 @@ extern "C" int mrl_policy_act(const mrl_net* net, const float* params, const mrl
     p.h.vrms_mean = value_rms->mean; p.h.vrms_var = value_rms->var; p.h.vrms_eps = value_rms->eps;
     p.clamp_lo = value_rms->clamp_lo; p.clamp_hi = value_rms->clamp_hi;
   }
-  if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  if (hact_ready) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_NONE>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
+  else if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNELU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(N, 128), 1, towers), s);
   MRL_CHECK_LAUNCH("mrl_policy_act");
@@ -1909,11 +1933,12 @@ extern "C" int mrl_policy_mean(const mrl_net* net, const float* params, const mr
     lo = obs_rms->clamp_lo; hi = obs_rms->clamp_hi;
     hipLaunchKernelGGL(rms_to_f32_kernel, dim3((O + 63) / 64), dim3(64), 0, s, obs_rms->mean, obs_rms->var, obs_rms->eps, O, mean_f, std_f);
   }
-  const unsigned short* wpl = (L.has_norm && rows > MRL_SMALL_M) ? launch_split_params(L, W, ws, params, s) : nullptr;
+  const bool hact_ready = net->tower_kind > MRL_TOWER_LAYERNORM_ELU;
+  const unsigned short* wpl = (L.has_norm && rows > MRL_SMALL_M && !chain_ok(net, rows, 1)) ? launch_split_params(L, W, ws, params, s) : nullptr;
   launch_towers_fwd(net, L, W, ws, params, obs, rows, mean_f, std_f, lo, hi, 0, 1, s, wpl);
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.A[0] = ws + W.xhat[0][last];
+  p.A[0] = hact_ready ? ws + W.hact[0][last] : ws + W.xhat[0][last];
   p.B[0] = params + L.Wh[0];
   p.pro0[0] = L.has_norm ? params + L.g[0][last] : nullptr;
   p.pro1[0] = L.has_norm ? params + L.be[0][last] : nullptr;
@@ -1927,7 +1952,8 @@ extern "C" int mrl_policy_mean(const mrl_net* net, const float* params, const mr
   p.h.raw_mu = 1;
   p.h.mu = mu_out;
   p.h.out_rs = A; p.h.out_off = 0;
-  if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
+  if (hact_ready) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_NONE>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
+  else if (net->tower_kind == MRL_TOWER_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_ELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
   else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNELU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
   else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_ACT, PRO_LNSILU>(p, dim3((unsigned)cdiv(rows, 128), 1, 1), s);
   MRL_CHECK_LAUNCH("mrl_policy_mean");
@@ -2102,9 +2128,7 @@ static void launch_chain_bwd(const mrl_net* net, const ParamLayout& L, const Wor
     MRL_PROF_STREAM("mrl::chain_bwd_kernel", s);
     const dim3 grid((unsigned)cdiv(mb, CH_ROWS), towers);
     const size_t lds = chain_lds_bytes(p.ld) + chain_bwd_extra_lds(p.ld);
-    if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-    else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-    else hipLaunchKernelGGL(chain_bwd_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+    MRL_CHAIN_LAUNCH(chain_bwd_kernel, net->tower_kind, grid, lds, s, p);
   }
   if (wgrad) launch_chain_wgrad(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw0, towers, s);
 }
@@ -2146,7 +2170,7 @@ static void launch_chain_wgrad(const mrl_net* net, const ParamLayout& L, const W
         cd.src = ws + W.colblk[tw0 + t][l]; cd.dst = ws + W.colpart[tw0 + t][l];
         cd.n4 = 3 * net->units[l] / 4; cd.nblk = nblk; cd.groups = W.col_groups;
         cd.task0 = task;
-        task += (int)cdiv((int64_t)cd.n4 * cd.groups, 512);
+        task += (int)cdiv((int64_t)cd.n4 * cd.groups, 1024);
       }
     if (pl.split_bf16) {
       MRL_PROF_STREAM("mrl::wgrad_group_kernel", s);
@@ -2515,6 +2539,7 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
   // small batches: the weights re-blocked for the chain kernels, once per call for the forward and the backward pass; with both
   // chains on (MRL_CHAIN bit 4: in one launch with the heads between them)
   const bool ch_f = chain_ok(net, mb, 1), ch_b = chain_ok(net, mb, 2), fused = ch_f && ch_b && (chain_mask() & 4) != 0;
+  if (net->tower_kind > MRL_TOWER_LAYERNORM_ELU && !fused) MRL_FAIL(MRL_EINVAL, "tower_kind %d needs the one-launch chain (at most %d layers)", net->tower_kind, CH_MAXL);
   const int hblocks = (int)cdiv(mb, fused ? CH_ROWS : 128);   // row blocks of the kernel that evaluates the heads
   auto fill_heads = [&](HeadsP& h) {
     h.seeds[0] = ws + W.seeds[0];
@@ -2570,7 +2595,7 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
   const std::function<void(hipStream_t)> metrics_hook = launch_metrics;
   bool metrics_done = false;
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
-  const bool planes = L.has_norm && mb > MRL_SMALL_M;
+  const bool planes = L.has_norm && mb > MRL_SMALL_M && !chain_ok(net, mb, 1);
   const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
   if (blocked_valid) {
     if (!fused || merge) MRL_FAIL(MRL_EINVAL, "internal: re-blocked weights can only be carried between the steps of the one-launch chain");
@@ -2596,9 +2621,7 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
       MRL_PROF_STREAM("mrl::ppo_chain_kernel", s);
       const dim3 grid((unsigned)(p.f.rows_written / CH_ROWS), 2);
       const size_t lds = chain_lds_bytes(p.f.ld) + CH_HEADS_F * sizeof(float) + chain_bwd_extra_lds(p.f.ld);
-      if (net->tower_kind == MRL_TOWER_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_PLAIN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-      else if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_ELU>, grid, dim3(64 * CH_WAVES), lds, s, p);
-      else hipLaunchKernelGGL(ppo_chain_kernel<CH_LN_SILU>, grid, dim3(64 * CH_WAVES), lds, s, p);
+      MRL_CHAIN_LAUNCH(ppo_chain_kernel, net->tower_kind, grid, lds, s, p);
     }
     launch_chain_wgrad(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s);
     MetricsArgs ma;
@@ -2660,6 +2683,15 @@ __global__ __launch_bounds__(256) void adam_reblock_kernel(float* __restrict__ p
   }
   __shared__ double s_red[256];
   __shared__ float s_coef;
+  const int nblk = gridDim.x - (tab.has_merge ? 1 : 0);
+  const int64_t n4 = n >> 2;   // the host checks n % 4 == 0 and the alignment
+  // the operands of the thread's first chunk are requested before the norm partials are reduced: one memory round trip less
+  const int64_t cfirst = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  f32x4 g4 = {0.f, 0.f, 0.f, 0.f}, p4 = g4, m4 = g4, v4 = g4;
+  if (cfirst < n4) {
+    g4 = *reinterpret_cast<const f32x4*>(g + 4 * cfirst);
+    p4 = *reinterpret_cast<f32x4*>(p + 4 * cfirst); m4 = *reinterpret_cast<f32x4*>(m + 4 * cfirst); v4 = *reinterpret_cast<f32x4*>(v + 4 * cfirst);
+  }
   s_red[threadIdx.x] = (((int)threadIdx.x < a.nparts) ? norm_part[threadIdx.x] : 0.0) + (((int)threadIdx.x + 256 < a.nparts) ? norm_part[threadIdx.x + 256] : 0.0);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -2675,11 +2707,11 @@ __global__ __launch_bounds__(256) void adam_reblock_kernel(float* __restrict__ p
   }
   __syncthreads();
   const float coef = s_coef;
-  const int nblk = gridDim.x - (tab.has_merge ? 1 : 0);
-  const int64_t n4 = n >> 2;   // the host checks n % 4 == 0 and the alignment
-  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (int64_t)nblk * 256) {
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * c);
-    f32x4 p4 = *reinterpret_cast<f32x4*>(p + 4 * c), m4 = *reinterpret_cast<f32x4*>(m + 4 * c), v4 = *reinterpret_cast<f32x4*>(v + 4 * c);
+  for (int64_t c = cfirst; c < n4; c += (int64_t)nblk * 256) {
+    if (c != cfirst) {
+      g4 = *reinterpret_cast<const f32x4*>(g + 4 * c);
+      p4 = *reinterpret_cast<f32x4*>(p + 4 * c); m4 = *reinterpret_cast<f32x4*>(m + 4 * c); v4 = *reinterpret_cast<f32x4*>(v + 4 * c);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gi = mul_rn(mul_rn(g4[e], a.grad_scale), coef);

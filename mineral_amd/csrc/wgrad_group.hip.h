@@ -208,32 +208,6 @@ __device__ __forceinline__ void wgrad_group_task(const WgTileP& p, const WgTileD
   }
 }
 
-// the tasks behind the tiles: sums of the backward chain's per-block column sums (WgColDesc)
-__device__ __forceinline__ void wgrad_col_task(const WgTileP& p, int task) {
-  int ci = 0;
-  for (int q = 1; q < p.ncd; ++q)
-    if (task >= p.cd[q].task0) ci = q;
-  const WgColDesc& cdsc = p.cd[ci];
-  const int idx = (task - cdsc.task0) * 512 + threadIdx.x;
-  const int grp = idx / cdsc.n4, ch = idx - grp * cdsc.n4;
-  if (grp >= cdsc.groups) return;
-  const int per = (cdsc.nblk + cdsc.groups - 1) / cdsc.groups;
-  const int b0 = grp * per, b1 = min(cdsc.nblk, b0 + per);
-  const float* src = cdsc.src + 4 * (int64_t)ch;
-  const int64_t stride = 4 * (int64_t)cdsc.n4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int b = b0;
-  for (; b + 16 <= b1; b += 16) {
-    f32x4 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (b + u) * stride);
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += v[u];
-  }
-  for (; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(src + b * stride);
-  *reinterpret_cast<f32x4*>(cdsc.dst + grp * stride + 4 * ch) = s;
-}
-
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgTileP p) {
   extern __shared__ __attribute__((aligned(16))) char wgg_lds[];
   // blocks are handed to the 8 XCDs in turn: remapped so that every XCD works on one contiguous eighth of the task list (the

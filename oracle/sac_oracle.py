@@ -28,9 +28,10 @@ class TowerCfg:
 
 
 class SACConfig:
-    def __init__(self, obs_dim, act_dim, actor_units, critic_units, n_critics=2, minlogstd=-5.0, maxlogstd=2.0):
+    def __init__(self, obs_dim, act_dim, actor_units, critic_units, n_critics=2, minlogstd=-5.0, maxlogstd=2.0, actor_kind=('LayerNorm', 'SiLU'),
+                 critic_kind=('LayerNorm', 'SiLU')):
         self.obs_dim, self.act_dim, self.n_critics = obs_dim, act_dim, n_critics
-        self.actor, self.critic = TowerCfg(actor_units), TowerCfg(critic_units)
+        self.actor, self.critic = TowerCfg(actor_units, *actor_kind), TowerCfg(critic_units, *critic_kind)   # (norm_type, act_type) of the mlp_kwargs
         self.minlogstd, self.maxlogstd = minlogstd, maxlogstd
 
 
@@ -50,9 +51,10 @@ class SACHParams:
 def actor_shapes(cfg):
     res, in_f = [], cfg.obs_dim
     for i, u in enumerate(cfg.actor.units):
-        b = i * 3
-        res += [(f'actor_mlp.mlp.{b}.weight', (u, in_f)), (f'actor_mlp.mlp.{b}.bias', (u,)), (f'actor_mlp.mlp.{b + 1}.weight', (u,)),
-                (f'actor_mlp.mlp.{b + 1}.bias', (u,))]
+        b = i * cfg.actor.layer_stride
+        res += [(f'actor_mlp.mlp.{b}.weight', (u, in_f)), (f'actor_mlp.mlp.{b}.bias', (u,))]
+        if cfg.actor.norm_type is not None:
+            res += [(f'actor_mlp.mlp.{b + 1}.weight', (u,)), (f'actor_mlp.mlp.{b + 1}.bias', (u,))]
         in_f = u
     return res + [('mu.weight', (cfg.act_dim, in_f)), ('mu.bias', (cfg.act_dim,)), ('sigma.weight', (cfg.act_dim, in_f)), ('sigma.bias', (cfg.act_dim,))]
 
@@ -63,11 +65,12 @@ def critic_shapes(cfg):
     for c in range(cfg.n_critics):
         in_f = cfg.obs_dim + cfg.act_dim
         for i, u in enumerate(cfg.critic.units):
-            b = i * 3
-            res += [(f'critics.{c}.mlp.{b}.weight', (u, in_f)), (f'critics.{c}.mlp.{b}.bias', (u,)), (f'critics.{c}.mlp.{b + 1}.weight', (u,)),
-                    (f'critics.{c}.mlp.{b + 1}.bias', (u,))]
+            b = i * cfg.critic.layer_stride
+            res += [(f'critics.{c}.mlp.{b}.weight', (u, in_f)), (f'critics.{c}.mlp.{b}.bias', (u,))]
+            if cfg.critic.norm_type is not None:
+                res += [(f'critics.{c}.mlp.{b + 1}.weight', (u,)), (f'critics.{c}.mlp.{b + 1}.bias', (u,))]
             in_f = u
-        b = 3 * len(cfg.critic.units)
+        b = cfg.critic.layer_stride * len(cfg.critic.units)
         res += [(f'critics.{c}.mlp.{b}.weight', (1, in_f)), (f'critics.{c}.mlp.{b}.bias', (1,))]
     return res
 
@@ -105,7 +108,7 @@ def q_values(pc, x, a, cfg):
     out = []
     for c in range(cfg.n_critics):
         h = P.mlp_forward(pc, f'critics.{c}', inp, cfg.critic)
-        b = 3 * len(cfg.critic.units)
+        b = cfg.critic.layer_stride * len(cfg.critic.units)
         out.append(F.linear(h, pc[f'critics.{c}.mlp.{b}.weight'], pc[f'critics.{c}.mlp.{b}.bias']))
     return out
 

@@ -66,6 +66,13 @@ NETS = {
     # LayerNorm + ELU towers (mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) in the PPO ActorCritic
     'mid_lnelu': dict(obs=64, act=12, units=[128, 64, 32], actf='ELU'),
     'full_lnelu': dict(obs=64, act=12, units=[512, 256, 128], actf='ELU'),
+    # the other norm_type / act_type combinations of mineral/nets/mlp.py:5-22 (chain kernels at every batch size)
+    'mid_silu': dict(obs=64, act=12, units=[128, 64, 32], norm=None, actf='SiLU'),
+    'full_silu': dict(obs=64, act=12, units=[512, 256, 128], norm=None, actf='SiLU'),
+    'mid_lnrelu': dict(obs=64, act=12, units=[128, 64, 32], actf='ReLU'),
+    'full_relu': dict(obs=64, act=12, units=[512, 256, 128], norm=None, actf='ReLU', fixed=True),
+    'full_lntanh': dict(obs=64, act=12, units=[512, 256, 128], actf='Tanh'),
+    'mid_tanh': dict(obs=20, act=3, units=[256, 64], norm=None, actf='Tanh'),
 }
 
 
@@ -174,7 +181,9 @@ def test_batch_moments_groups(hip):
 @pytest.mark.parametrize('net,N,dist', [('mid', 64, 'dreamerv3_normal'), ('full', 16, 'dreamerv3_normal'), ('full', 300, 'normal'),
                                        ('wide2', 129, 'dreamerv3_normal'), ('cartpole', 100, 'normal'), ('elu_wide', 300, 'normal'),
                                        ('elu_head', 77, 'dreamerv3_normal'), ('ln_fixed', 64, 'normal'),
-                                       ('mid_lnelu', 16, 'dreamerv3_normal'), ('full_lnelu', 300, 'normal')])
+                                       ('mid_lnelu', 16, 'dreamerv3_normal'), ('full_lnelu', 300, 'normal'),
+                                       ('mid_silu', 70, 'dreamerv3_normal'), ('full_relu', 300, 'normal'), ('full_lntanh', 9000, 'dreamerv3_normal'),
+                                       ('mid_tanh', 33, 'normal')])
 def test_policy_act(hip, golden, net, N, dist):
     from mineral_amd.common.normalizers import RunningMeanStd
     spec = NETS[net]
@@ -278,6 +287,15 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
     ('odd_heads', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    # no norm + SiLU, LayerNorm / no norm + ReLU, LayerNorm / no norm + Tanh: small batches and batches above 8192 rows
+    ('mid_silu', 64, 8, 128, 'dreamerv3_normal', 0, 'bound'),
+    ('full_silu', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('mid_lnrelu', 37, 8, 296, 'normal', 1, 'reg'),
+    ('full_relu', 64, 8, 256, 'normal', 0, 'bound'),
+    ('full_relu', 1041, 8, 8328, 'normal', 0, 'bound'),
+    ('full_lntanh', 64, 8, 256, 'dreamerv3_normal', 0, 'bound'),
+    ('full_lntanh', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('mid_tanh', 50, 8, 200, 'normal', 0, 'bound'),
     # the benchmark's own launches: the DFlexAntPPO network on 32768-row minibatches (256-block weight-gradient plans, 256-row
     # tiles, 256 row tiles per tower), as the only minibatch of the batch and as the second of two (row0 = 32768)
     ('full', 1024, 32, 32768, 'dreamerv3_normal', 0, 'bound'),
@@ -563,19 +581,24 @@ def test_observation_width_that_is_not_a_multiple_of_4(hip, tmp_path):
     assert float(pad.abs().max()) == 0.0, 'weights of the padding columns stay zero'
 
 
-def test_end_to_end_training_above_8192_rows_vs_oracle(hip, tmp_path):
+@pytest.mark.parametrize('net,N,T,mb', [('full', 1024, 32, 16384), ('full_silu', 1024, 32, 16384), ('mid_lnrelu', 64, 8, 128), ('mid_tanh', 64, 8, 128)])
+def test_end_to_end_training_above_8192_rows_vs_oracle(hip, tmp_path, net, N, T, mb):
     """One PPO.train() epoch of the product against the oracle's on the deterministic env with minibatches of 16,384 rows: the
     regime of the per-layer kernels (split-bf16 GEMMs, streamed LayerNorm backward, any-order weight-gradient launches), which
-    the reference's own fixtures (64 envs) do not reach.  DFlexAntPPO network, 1,024 envs x 32 steps, 2 mini-epochs."""
+    the reference's own fixtures (64 envs) do not reach.  DFlexAntPPO network, 1,024 envs x 32 steps, 2 mini-epochs.  Also the
+    tower kinds that have no reference fixture (no norm + SiLU at 16,384 rows, LayerNorm + ReLU and no norm + Tanh at 128):
+    rollout, GAE, statistics, losses, KL-adaptive rate and optimizer against the oracle's whole epoch."""
     from mineral_amd.agents import PPO
     from test_oracle_golden import run_oracle_training
-    spec = NETS['full']
-    ospec = dict(obs=spec['obs'], act=spec['act'], units=spec['units'], norm='LayerNorm', act_type='SiLU', fixed_sigma=False, dist_type='dreamerv3_normal')
-    N, T, mb, mini_epochs, epochs = 1024, 32, 16384, 2, 1
-    cfg = _agent_cfg(spec, N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
+    spec = NETS[net]
+    has_norm = spec.get('norm', 'LayerNorm') is not None
+    ospec = dict(obs=spec['obs'], act=spec['act'], units=spec['units'], norm=spec.get('norm', 'LayerNorm'), act_type=spec.get('actf', 'SiLU'), fixed_sigma=False,
+                 dist_type='dreamerv3_normal')
+    mini_epochs, epochs = 2, 1
+    cfg = _agent_cfg(dict(spec, fixed=False), N, T, mb, mini_epochs, epochs, 'AdamW', str(tmp_path))
     env = synth.GoldenEnv(N, spec['obs'], spec['act'], device=DEV)
     agent = PPO(cfg, logdir=str(tmp_path), accelerator=None, datasets=None, env=env)
-    agent.model.load_state_dict(synth.make_params(synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], True, True, False), 5))
+    agent.model.load_state_dict(synth.make_params(synth.actor_critic_shapes(spec['obs'], spec['act'], spec['units'], has_norm, True, False), 5))
     agent.noise_fn = lambda k, shape: synth.gaussianish(shape, 900 + k).to(DEV)
     agent.save = lambda *a, **k: None
     agent._checkpoint_save = lambda *a, **k: None

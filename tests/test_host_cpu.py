@@ -94,10 +94,14 @@ def test_parameter_views_match_reference_names_and_count():
     assert float(c.state_dict()['sigma'].abs().sum()) == 0            # models.py:87-88
     e = ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='ELU'), fixed_sigma=True, device='cpu')
     assert e.net.tower_kind == 2 and 'mu.weight' in e.state_dict()    # LayerNorm + ELU towers: same layout as LayerNorm + SiLU
+    # every norm_type in {None, LayerNorm} x act_type in {SiLU, ELU, ReLU, Tanh} of mlp.py:5-22 has kernels
+    t = ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='Tanh'), fixed_sigma=True, device='cpu')
+    r = ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ReLU'), fixed_sigma=False, device='cpu')
+    assert (t.net.tower_kind, r.net.tower_kind) == (6, 5) and 'actor_mlp.mlp.1.weight' in t.state_dict() and 'actor_mlp.mlp.1.weight' not in r.state_dict()
     with pytest.raises(NotImplementedError):                           # pairs without kernels
-        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='LayerNorm', act_type='Tanh'), fixed_sigma=True, device='cpu')
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type='BatchNorm1d', act_type='ReLU'), fixed_sigma=True, device='cpu')
     with pytest.raises(NotImplementedError):
-        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='ReLU'), fixed_sigma=False, device='cpu')
+        ActorCritic({'obs': (64,)}, 12, mlp_kwargs=dict(units=[32], norm_type=None, act_type='GELU'), fixed_sigma=False, device='cpu')
 
 
 def test_schedulers_match_reference_tables(golden):

@@ -40,18 +40,19 @@ def pack(params, shapes, net, which):
 
 def layout_names(net, which):
     """Parameter names in the order of mrl_sac_param_offsets."""
+    norm_kinds = (0, 2, 4, 6)      # the MRL_TOWER_* kinds with a LayerNorm (its gain / bias follow every Linear)
     if which == 0:
-        names = []
+        names, norm = [], net.actor_kind in norm_kinds
         for l in range(net.actor_layers):
-            b = 3 * l
-            names += [f'actor_mlp.mlp.{b}.weight', f'actor_mlp.mlp.{b}.bias', f'actor_mlp.mlp.{b + 1}.weight', f'actor_mlp.mlp.{b + 1}.bias']
+            b = (3 if norm else 2) * l
+            names += [f'actor_mlp.mlp.{b}.weight', f'actor_mlp.mlp.{b}.bias'] + ([f'actor_mlp.mlp.{b + 1}.weight', f'actor_mlp.mlp.{b + 1}.bias'] if norm else [])
         return names + ['HEAD.weight', 'HEAD.bias']
-    names = []
+    names, norm = [], net.critic_kind in norm_kinds
     for c in range(2):
         for l in range(net.critic_layers):
-            b = 3 * l
-            names += [f'critics.{c}.mlp.{b}.weight', f'critics.{c}.mlp.{b}.bias', f'critics.{c}.mlp.{b + 1}.weight', f'critics.{c}.mlp.{b + 1}.bias']
-    b = 3 * net.critic_layers
+            b = (3 if norm else 2) * l
+            names += [f'critics.{c}.mlp.{b}.weight', f'critics.{c}.mlp.{b}.bias'] + ([f'critics.{c}.mlp.{b + 1}.weight', f'critics.{c}.mlp.{b + 1}.bias'] if norm else [])
+    b = (3 if norm else 2) * net.critic_layers
     for c in range(2):
         names += [f'critics.{c}.mlp.{b}.weight', f'critics.{c}.mlp.{b}.bias']
     return names
@@ -82,11 +83,27 @@ def rel_err(a, b):
                                           (64, 12, [512, 256, 128], [512, 256, 128], 8200),   # above 8,192 rows: the split-bf16 GEMMs, incl. the input gradient through the critic
                                           (64, 12, [512, 256, 128], [512, 256, 128], 2048)])  # the batch and networks of cfgs/agent/DFlexAntSAC.yaml
 def test_sac_gradients_vs_oracle(O, A, au, cu, B):
+    _sac_gradients_vs_oracle(O, A, au, cu, B, ('LayerNorm', 'SiLU'), ('LayerNorm', 'SiLU'))
+
+
+@pytest.mark.parametrize('O,A,au,cu,B,ak,ck', [
+    (64, 12, [512, 256, 128], [512, 256, 128], 2048, ('LayerNorm', 'ELU'), ('LayerNorm', 'ELU')),   # the mlp_kwargs of DFlexAntSHAC.yaml in the SAC towers
+    (64, 12, [512, 256, 128], [512, 256, 128], 300, (None, 'SiLU'), (None, 'SiLU')),
+    (8, 4, [64, 32], [64, 32], 48, (None, 'ELU'), ('LayerNorm', 'ReLU')),                            # actor and critic of different kinds
+    (12, 4, [128], [256, 64], 129, ('LayerNorm', 'Tanh'), (None, 'ReLU')),
+    (64, 12, [256, 128], [256, 128], 8200, (None, 'SiLU'), ('LayerNorm', 'ELU'))])                   # above 8,192 rows
+def test_sac_gradients_vs_oracle_other_tower_kinds(O, A, au, cu, B, ak, ck):
+    """The norm_type / act_type combinations of mineral/nets/mlp.py:5-22 in the SAC actor and critics (the shipped DFlexAntSAC.yaml
+    uses LayerNorm + SiLU): sampling, both losses and all gradients against the oracle's autograd."""
+    _sac_gradients_vs_oracle(O, A, au, cu, B, ak, ck)
+
+
+def _sac_gradients_vs_oracle(O, A, au, cu, B, ak, ck):
     from mineral_amd import _hip
     L = _hip.lib()
-    cfg = S.SACConfig(O, A, au, cu)
+    cfg = S.SACConfig(O, A, au, cu, actor_kind=ak, critic_kind=ck)
     hp = S.SACHParams()
-    net = _hip.make_sac_net(O, A, au, cu)
+    net = _hip.make_sac_net(O, A, au, cu, actor_kind=_hip.TOWER_KINDS[ak], critic_kind=_hip.TOWER_KINDS[ck])
     pa = synth.make_params(S.actor_shapes(cfg), 31)
     pc = synth.make_params(S.critic_shapes(cfg), 32)
     pt = synth.make_params(S.critic_shapes(cfg), 33)
