@@ -160,7 +160,7 @@ class PPO(Agent):
 
         # --- Multi-GPU (ppo.py:115-123): no wrapper objects; see _sync_* below ---
         self._dist = None
-        if self.multi_gpu and self.rank_size > 1:
+        if self.multi_gpu:   # also with a group of one rank: the collectives then run (through RCCL) on this rank's own data
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError('multi_gpu=True needs an initialised torch.distributed process group (backend nccl)')
