@@ -160,7 +160,8 @@ struct WgradPlan { int bm, bn, tiles_m, tiles_n, nsplit, ksplit; };
 // MRL_CHAIN in the environment (read once) is a bit mask for A/B measurements: 1 forward chain, 2 backward chain + weight
 // gradients, 4 (with both) forward, heads and backward of a PPO step in one launch; default 7.  The workspace layout (column-partial blocks, slab counts) follows bit 1, so it cannot change while a
 // process runs.
-constexpr int MRL_SMALL_M = 8192;
+// (MRL_SMALL_M in the environment, read once, moves the boundary for A/B runs: tools/threshold_ab.sh)
+static const int MRL_SMALL_M = [] { const char* e = getenv("MRL_SMALL_M"); return e ? atoi(e) : 8192; }();
 static int chain_mask() {
   static const int m = [] { const char* e = getenv("MRL_CHAIN"); return e ? atoi(e) : 7; }();
   return m;
