@@ -3,6 +3,7 @@
 #include "../../include/mineral_ppo.h"
 #include "gemm.hip.h"
 #include "split_bf16.hip.h"
+#include "ln_wgrad0.hip.h"
 #include "chain.hip.h"
 #include "wgrad_group.hip.h"
 
@@ -173,6 +174,16 @@ static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
   return (chain_mask() & bit) == bit && (rows <= MRL_SMALL_M || net->tower_kind > MRL_TOWER_LAYERNORM_ELU) && net->n_layers <= CH_MAXL &&
          net->obs_dim <= 512;   // LDS tiles of at most 512 columns
 }
+// A first layer of 512 LayerNorm outputs on 64 inputs, on batches above MRL_SMALL_M rows: its LayerNorm backward and its weight
+// gradient are one launch (ln_wgrad0.hip.h); slabs and column partials are then per row range of that launch.
+// MRL_FUSED_FIRST=0 in the environment (read once) keeps the two launches, for A/B runs.
+static bool first_fused(const mrl_net* net, const int* in_dim, int64_t rows) {
+  static const bool on = [] { const char* e = getenv("MRL_FUSED_FIRST"); return e ? atoi(e) != 0 : true; }();
+  return on && rows > MRL_SMALL_M && net->units[0] == LNWG0_N && in_dim[0] == 64 &&
+         (net->tower_kind == MRL_TOWER_LAYERNORM_SILU || net->tower_kind == MRL_TOWER_LAYERNORM_ELU) && !chain_ok(net, rows, 2);
+}
+// rows per block of that launch: about 128 blocks per tower (one block per CU with two towers), whole 16-row steps
+static int first_fused_rows(int64_t rows) { return (int)std::max<int64_t>(64, cdiv(cdiv(rows, 128), 16) * 16); }
 // 64 x 64 weight-gradient tiles of one tower (layers + head) and the row ranges they are split into: about 1,024 wave tasks
 // for two towers (one per SIMD: the launch keeps one block of four waves per CU), at least 64 rows each, whole multiples of 32 rows
 static int chain_wgrad_tiles(const mrl_net* net, const int* in_dim) {
@@ -305,9 +316,12 @@ static void workspace_layout(const mrl_net* net, int64_t rows, Workspace* w) {
       } else if (chain_bwd) w->rowblocks[l] = ch_nsplit;                                      // column partials per row range of the weight-gradient launch
       else if (net->tower_kind == MRL_TOWER_ELU) w->rowblocks[l] = (int)cdiv(rows, fwd_bm(u));   // full-row tiles of the fused dgrad
       else w->rowblocks[l] = ln_bwd_streamed(u) ? (int)cdiv(rows, ln_bwd_rows(rows)) : (int)cdiv(rows, fused_bwd_rows(u, rows));
+      const bool fused0 = l == 0 && first_fused(net, L.in_dim, rows);
+      if (fused0) w->rowblocks[l] = (int)cdiv(rows, first_fused_rows(rows));
       w->colpart[tw][l] = o; o = align64(o + (int64_t)w->rowblocks[l] * 3 * u);
       w->wp[l] = wgrad_plan(u, L.in_dim[l], rows);
       if (chain_bwd) { w->wp[l].nsplit = tile_wg ? tp.nsplit[l] : ch_nsplit; w->wp[l].ksplit = ch_ksplit; }
+      if (fused0) { w->wp[l].nsplit = w->rowblocks[l]; w->wp[l].ksplit = first_fused_rows(rows); }   // one slab per block of the fused launch
       w->slab[tw][l] = o; o = align64(o + (int64_t)w->wp[l].nsplit * u * L.in_dim[l]);
     }
     w->seeds[tw] = o; o = align64(o + rows * 32);
@@ -2279,6 +2293,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
   // that stream before it reduces the slabs.
   const bool pair_wgrad = wgrad && !(wgrad_stream && wgrad_events) && any_order_enabled();
   const bool side_wgrad = wgrad && ((wgrad_stream && wgrad_events) || pair_wgrad);
+  bool first_done = false;   // the first layer's weight gradient came out of the fused LayerNorm-backward launch
   int pending = -1;   // pair_wgrad: the layer whose weight gradient goes out right behind the next dgrad launch, beside it
   auto wgrad_beside = [&](int l) {
     if (pair_wgrad) { pending = l; return; }
@@ -2358,6 +2373,32 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
         else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, grid, s);
       }
       flush_pending(true);
+      if (l == 0 && wgrad && first_fused(net, L.in_dim, mb)) {
+        // first layer: LayerNorm backward and weight gradient in one launch; dZ is only stored for an input-gradient launch
+        LnWg0Args f;
+        memset(&f, 0, sizeof(f));
+        for (int k = 0; k < towers; ++k) {
+          const int tw = tw0 + k;
+          f.dh[k] = ws + W.dz[tw][0]; f.dz_out[k] = input_grad ? ws + W.dz[tw][0] : nullptr;
+          f.xhat[k] = ws + W.xhat[tw][0]; f.rstd[k] = ws + W.rstd[tw][0];
+          f.gamma[k] = params + L.g[tw][0]; f.beta[k] = params + L.be[tw][0];
+          f.slab[k] = ws + W.slab[tw][0]; f.colpart[k] = ws + W.colpart[tw][0];
+        }
+        f.x = x; f.mean = obs_mean; f.std = obs_std; f.clamp_lo = clamp_lo; f.clamp_hi = clamp_hi;
+        f.M = (int)mb; f.rows_per_block = first_fused_rows(mb);
+        static const bool lds_ok = [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnbwd_wgrad0_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnbwd_wgrad0_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          return true;
+        }();
+        (void)lds_ok;
+        const dim3 fgrid(W.rowblocks[0], towers);
+        MRL_PROF_STREAM("lnbwd_wgrad0_kernel", s);
+        if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL((lnbwd_wgrad0_kernel<64, true>), fgrid, dim3(LNWG0_THREADS), LnWg0Lds<64>::BYTES, s, f);
+        else hipLaunchKernelGGL((lnbwd_wgrad0_kernel<64, false>), fgrid, dim3(LNWG0_THREADS), LnWg0Lds<64>::BYTES, s, f);
+        first_done = true;
+        continue;
+      }
       LnBwdArgs a;
       memset(&a, 0, sizeof(a));
       for (int k = 0; k < towers; ++k) {
@@ -2365,7 +2406,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
         a.dz[k] = ws + W.dz[tw][l]; a.xhat[k] = ws + W.xhat[tw][l]; a.rstd[k] = ws + W.rstd[tw][l];
         a.gamma[k] = params + L.g[tw][l]; a.beta[k] = params + L.be[tw][l]; a.colpart[k] = ws + W.colpart[tw][l];
       }
-      a.M = (int)mb; a.rows_per_block = ln_bwd_rows(mb);
+      a.M = (int)mb; a.rows_per_block = (l == 0 && first_fused(net, L.in_dim, mb)) ? first_fused_rows(mb) : ln_bwd_rows(mb);   // = the row ranges of W.rowblocks
       a.act_elu = net->tower_kind == TOWER_LAYERNORM_ELU;
       dim3 grid(W.rowblocks[l], towers);
       if (u == 512) { MRL_PROF_STREAM("ln_bwd_kernel<512>", s); hipLaunchKernelGGL(ln_bwd_kernel<512>, grid, dim3(256), 0, s, a); }
@@ -2390,7 +2431,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
   }
   flush_pending(false);   // the first layer's weight gradient when no launch is left to run beside
   if (!wgrad || side_wgrad) return;
-  for (int l = last + 1; l >= 0; --l) wgrad_of(l, s);
+  for (int l = last + 1; l >= (first_done ? 1 : 0); --l) wgrad_of(l, s);
 }
 
 // Fixed-order reduction of the partial slabs, column partials and head-bias partials of towers tw0 .. tw0+towers-1

@@ -21,6 +21,10 @@ CASES = [('mid', 64, 8, 128, 'dreamerv3_normal'), ('full', 64, 8, 256, 'dreamerv
          ('full', 64, 32, 2048, 'dreamerv3_normal'), ('cartpole', 37, 8, 296, 'normal'), ('elu_head', 64, 8, 256, 'dreamerv3_normal'),
          ('full_lnelu', 64, 8, 256, 'normal'), ('ln_fixed', 64, 8, 256, 'normal'), ('obs128', 100, 8, 800, 'normal')]
 
+# AB_BIG=1: batches above 8,192 rows instead (the per-layer kernel family; ragged row counts included)
+if os.environ.get('AB_BIG'):
+    CASES = [('full', 1024, 32, 16384, 'dreamerv3_normal'), ('full', 2048, 32, 32768, 'dreamerv3_normal'), ('full_lnelu', 1024, 32, 16384, 'normal'),
+             ('full', 1024, 32, 12000, 'dreamerv3_normal'), ('full', 1024, 32, 9999, 'dreamerv3_normal'), ('mid', 1024, 32, 16384, 'dreamerv3_normal')]
 
 def grads_of(case):
     import test_hip_parity as T
