@@ -702,10 +702,9 @@ __global__ void split_params_kernel(const float* __restrict__ params, int64_t n,
   kplanes[2 * stride + j] = l;
 }
 
-static unsigned short* launch_split_params(const ParamLayout& L, const Workspace& W, float* ws, const float* params, hipStream_t s) {
-  unsigned short* planes = reinterpret_cast<unsigned short*>(ws + W.wplanes);
+static SplitTable split_table(const ParamLayout& L) {
   SplitTable tab;
-  tab.n = 0;
+  memset(&tab, 0, sizeof(tab));
   int nl = 0;
   while (nl < MRL_MAX_LAYERS && L.in_dim[nl] > 0) ++nl;
   for (int tw = 0; tw < L.n_towers; ++tw)
@@ -714,6 +713,12 @@ static unsigned short* launch_split_params(const ParamLayout& L, const Workspace
       static_assert(MRL_MAX_SPLITDESC >= 2 * MRL_MAX_LAYERS, "one descriptor per weight matrix of two towers");
       if (L.in_dim[l] % 16 == 0) tab.d[tab.n++] = SplitDesc{L.W[tw][l], rows, L.in_dim[l]};
     }
+  return tab;
+}
+
+static unsigned short* launch_split_params(const ParamLayout& L, const Workspace& W, float* ws, const float* params, hipStream_t s) {
+  unsigned short* planes = reinterpret_cast<unsigned short*>(ws + W.wplanes);
+  const SplitTable tab = split_table(L);
   hipLaunchKernelGGL(split_params_kernel, dim3((unsigned)cdiv(L.total, 256)), dim3(256), 0, s, params, L.total, planes, W.wplane_stride,
                      planes + 3 * W.wplane_stride, tab);
   return planes;
@@ -2638,9 +2643,10 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
   bool metrics_done = false;
   // the parameter vector as three bf16 planes, once per call: read by the split-bf16 forward and input-gradient kernels
   const bool planes = L.has_norm && mb > MRL_SMALL_M && !chain_ok(net, mb, 1);
-  const unsigned short* wpl = planes ? launch_split_params(L, W, ws, params, s) : nullptr;
+  const unsigned short* wpl = !planes ? nullptr
+                              : (blocked_valid ? reinterpret_cast<const unsigned short*>(ws + W.wplanes) : launch_split_params(L, W, ws, params, s));
   if (blocked_valid) {
-    if (!fused || merge) MRL_FAIL(MRL_EINVAL, "internal: re-blocked weights can only be carried between the steps of the one-launch chain");
+    if (!(fused || planes) || merge) MRL_FAIL(MRL_EINVAL, "internal: derived weight copies can only be carried between the steps of one call");
   } else if (ch_f || ch_b) launch_reblock(net, L, W, ws, params, 0, 2, ch_f, ch_b, s, fused, merge);
   else if (merge)
     hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(1024), 0, s, merge->mean, merge->var, merge->count, merge->bmean, merge->bvar, merge->bcount,
@@ -2712,9 +2718,21 @@ extern "C" int mrl_ppo_grad(const mrl_net* net, const float* params, const mrl_p
 // run several optimizer steps back to back: chunks of the parameter vector that belong to a weight matrix go to their places in the
 // forward-order and backward-order copies as they are written.  One more block merges the next step's batch moments into the
 // running statistics.  Zero padding of the copies is never touched: a reblock_kernel launch must have written them once.
+// For the per-layer kernels of large batches the derived copies are the three bf16 planes of split_params_kernel, in both of
+// its orders: every chunk of four updated parameters is split (the same split, so the planes are bit-identical to a
+// split_params_kernel launch after the step) and stored as 8 bytes per plane and order.
 struct ArDesc { int c0, c1, K; float* fdst; int fsteps; float* bdst; int bJ, bsteps; };   // chunks [c0, c1) are a row-major [rows][K] matrix
 constexpr int AR_MAXDESC = 2 * (MRL_MAX_LAYERS + 1);
-struct ArTable { ArDesc d[AR_MAXDESC]; int n, has_merge; RmsMergeArgs merge; };
+struct ArTable {
+  ArDesc d[AR_MAXDESC];
+  int n, has_merge;
+  RmsMergeArgs merge;
+  // batches above MRL_SMALL_M rows: the bf16 planes of the parameter vector instead (split_params_kernel's two orders), or null
+  unsigned short* planes;
+  unsigned short* kplanes;
+  int64_t plane_stride;
+  SplitTable split;
+};
 
 __global__ __launch_bounds__(256) void adam_reblock_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, int64_t n, const double* __restrict__ norm_part,
@@ -2769,6 +2787,24 @@ __global__ __launch_bounds__(256) void adam_reblock_kernel(float* __restrict__ p
     *reinterpret_cast<f32x4*>(p + 4 * c) = p4;
     *reinterpret_cast<f32x4*>(m + 4 * c) = m4;
     *reinterpret_cast<f32x4*>(v + 4 * c) = v4;
+    if (tab.planes) {
+      u32x2 h, mm, l;
+      split_rne4(p4, h, mm, l);
+      *reinterpret_cast<u32x2*>(tab.planes + 4 * c) = h;
+      *reinterpret_cast<u32x2*>(tab.planes + tab.plane_stride + 4 * c) = mm;
+      *reinterpret_cast<u32x2*>(tab.planes + 2 * tab.plane_stride + 4 * c) = l;
+      int64_t j = 4 * c;                               // a chunk lies inside one 16-k run of a matrix row (K a multiple of 16, offsets of 4)
+      for (int q = 0; q < tab.split.n; ++q) {
+        const int64_t e = 4 * c - tab.split.d[q].off;
+        if (e >= 0 && e < (int64_t)tab.split.d[q].rows * tab.split.d[q].cols) {
+          const int row = (int)(e / tab.split.d[q].cols), k = (int)(e % tab.split.d[q].cols);
+          j = tab.split.d[q].off + (int64_t)(k >> 4) * tab.split.d[q].rows * 16 + (int64_t)row * 16 + (k & 15);
+        }
+      }
+      *reinterpret_cast<u32x2*>(tab.kplanes + j) = h;
+      *reinterpret_cast<u32x2*>(tab.kplanes + tab.plane_stride + j) = mm;
+      *reinterpret_cast<u32x2*>(tab.kplanes + 2 * tab.plane_stride + j) = l;
+    }
     int hit = -1;
     for (int q = 0; q < tab.n; ++q)
       if (c >= tab.d[q].c0 && c < tab.d[q].c1) hit = q;
@@ -2905,8 +2941,19 @@ extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_p
   const bool carry = chain_ok(net, mb, 3) && (chain_mask() & 4) != 0 && !chain_natural() && (L.total & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
                        reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+  // The per-layer kernels of large batches read the weights from bf16 planes: the optimizer keeps those current likewise.
+  const bool vec_ok = (L.total & 3) == 0 && ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+                                              reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+  static const bool carry_planes_on = [] { const char* e = getenv("MRL_CARRY_PLANES"); return e ? atoi(e) != 0 : true; }();
+  const bool carry_planes = !carry && carry_planes_on && vec_ok && L.has_norm && mb > MRL_SMALL_M && !chain_ok(net, mb, 1) && !chain_ok(net, mb, 2) && !tower_streams(mb);
   ArTable tab;
   memset(&tab, 0, sizeof(tab));
+  if (carry_planes) {
+    tab.planes = reinterpret_cast<unsigned short*>((float*)workspace + W.wplanes);
+    tab.plane_stride = W.wplane_stride;
+    tab.kplanes = tab.planes + 3 * W.wplane_stride;
+    tab.split = split_table(L);
+  }
   if (carry) {
     float* ws = (float*)workspace;
     const int nl = net->n_layers, U = net->units[nl - 1];
@@ -2927,14 +2974,14 @@ extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_p
   }
   for (int64_t i = 0; i < n_minibatches; ++i) {
     RmsMergeArgs m0;
-    const bool first = i == 0 || !carry;
+    const bool first = i == 0 || !(carry || carry_planes);
     if (obs_rms && first) m0 = merge_of(i);
     bool norm_ready = false;
     if (int rc = ppo_grad_impl(net, params, hp, buf, i * mb, mb, obs_mean_f32, obs_std_f32, clamp_lo, clamp_hi, grads, metrics_out + i * MRL_NMETRIC,
                                workspace, workspace_bytes, stream, &norm_ready, (obs_rms && first) ? &m0 : nullptr, !first))
       return rc;
     const double* prenorm = norm_ready ? (const double*)((const float*)workspace + W.norm_part) : nullptr;
-    const bool more = carry && i + 1 < n_minibatches;
+    const bool more = (carry || carry_planes) && i + 1 < n_minibatches;
     tab.has_merge = (more && obs_rms) ? 1 : 0;
     if (tab.has_merge) tab.merge = merge_of(i + 1);
     if (int rc = adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, first_step + i, max_norm, 1.0f,
