@@ -39,11 +39,12 @@ struct LnWg0Args {
   const float* rstd[2];
   const float* gamma[2];
   const float* beta[2];
-  const float* x;           // [rows][IN] layer input
+  const float* x;           // [rows][in] layer input
+  int in;                   // inputs per row: a multiple of 4, at most IN (the columns up to IN are zero operands)
   const float* mean;        // input normalisation (nullptr: the input is used as it is)
   const float* std;
   float clamp_lo, clamp_hi;
-  float* slab[2];           // [gridDim.x][512][IN]
+  float* slab[2];           // [gridDim.x][512][in]
   float* colpart[2];        // [gridDim.x][3][512]
   int M, rows_per_block;    // rows_per_block a multiple of 16
 };
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
   constexpr int N = LNWG0_N, TN = IN / 32;
   constexpr int AROW = Ld::AROW, APLANE = Ld::APLANE, AOPER = Ld::AOPER, BROW = Ld::BROW, BPLANE = Ld::BPLANE, WSTAGE = Ld::WSTAGE;
   constexpr int B_CPR = IN / 4;                        // 4-float chunks per input row
-  static_assert(IN == 64, "64 observations per row: one chunk per thread of the four row waves");
+  static_assert(IN == 64, "up to 64 observations per row: one chunk per thread of the first four row waves");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int t = threadIdx.x, lane = t & 63, tw = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
       b[c] = *reinterpret_cast<const f32x4*>(a.beta[tw] + 4 * (lane + 64 * c));
     }
     const int cbk = t % B_CPR, krb = t / B_CPR;        // this thread's chunk of the step's [16][IN] input tile (threads below 16 IN / 4)
-    const bool has_b = wave < BK * B_CPR / 64;
+    const bool has_b = wave < BK * B_CPR / 64, in_b = 4 * cbk < a.in;   // in_b: the chunk exists in the input rows
     const bool norm = a.mean != nullptr;
     f32x4 pv0 = {0.f, 0.f, 0.f, 0.f}, pv1 = {1.f, 1.f, 1.f, 1.f};
-    if (norm) {
+    if (norm && in_b) {
       pv0 = *reinterpret_cast<const f32x4*>(a.mean + 4 * cbk);
       pv1 = *reinterpret_cast<const f32x4*>(a.std + 4 * cbk);
     }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
       rr[i] = rs[row];
     };
     auto gload_in = [&](int st) __attribute__((always_inline)) {
-      if (has_b) ob = *reinterpret_cast<const f32x4*>(xin + (int64_t)min(r0 + st * BK + krb, a.M - 1) * IN + 4 * cbk);
+      if (has_b && in_b) ob = *reinterpret_cast<const f32x4*>(xin + (int64_t)min(r0 + st * BK + krb, a.M - 1) * a.in + 4 * cbk);
     };
     auto step = [&](int st, auto PAR) __attribute__((always_inline)) {
       constexpr int S = decltype(PAR)::value;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
           for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf((v[e] - pv0[e]) / pv1[e], a.clamp_lo), a.clamp_hi);
         }
         u32x2 h, m, l;
-        split4(base + krb < r1 ? v : zero, h, m, l);
+        split4((base + krb < r1 && in_b) ? v : zero, h, m, l);
         char* qb = buf + AOPER + krb * BROW + cbk * 8;
         *reinterpret_cast<u32x2*>(qb) = h;
         *reinterpret_cast<u32x2*>(qb + BPLANE) = m;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
       multiply(lds + (st & 1) * WSTAGE);
       __syncthreads();                                  // step st + 1 is staged; stage st & 1 may be written again
     }
-    float* out = a.slab[tw] + (int64_t)blockIdx.x * N * IN;
+    float* out = a.slab[tw] + (int64_t)blockIdx.x * N * a.in;
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(LNWG0_THREADS, 1) void lnbwd_wgrad0_kernel(const Ln
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = mw * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          out[row * IN + jn * 32 + col] = acc[i][jn][r];
+          if (jn * 32 + col < a.in) out[row * a.in + jn * 32 + col] = acc[i][jn][r];
         }
   }
   __syncthreads();

@@ -174,12 +174,12 @@ static bool chain_ok(const mrl_net* net, int64_t rows, int bit) {
   return (chain_mask() & bit) == bit && (rows <= MRL_SMALL_M || net->tower_kind > MRL_TOWER_LAYERNORM_ELU) && net->n_layers <= CH_MAXL &&
          net->obs_dim <= 512;   // LDS tiles of at most 512 columns
 }
-// A first layer of 512 LayerNorm outputs on 64 inputs, on batches above MRL_SMALL_M rows: its LayerNorm backward and its weight
+// A first layer of 512 LayerNorm outputs on at most 64 inputs, on batches above MRL_SMALL_M rows: its LayerNorm backward and its weight
 // gradient are one launch (ln_wgrad0.hip.h); slabs and column partials are then per row range of that launch.
 // MRL_FUSED_FIRST=0 in the environment (read once) keeps the two launches, for A/B runs.
 static bool first_fused(const mrl_net* net, const int* in_dim, int64_t rows) {
   static const bool on = [] { const char* e = getenv("MRL_FUSED_FIRST"); return e ? atoi(e) != 0 : true; }();
-  return on && rows > MRL_SMALL_M && net->units[0] == LNWG0_N && in_dim[0] == 64 &&
+  return on && rows > MRL_SMALL_M && net->units[0] == LNWG0_N && in_dim[0] <= 64 && in_dim[0] % 4 == 0 &&
          (net->tower_kind == MRL_TOWER_LAYERNORM_SILU || net->tower_kind == MRL_TOWER_LAYERNORM_ELU) && !chain_ok(net, rows, 2);
 }
 // rows per block of that launch: about 128 blocks per tower (one block per CU with two towers), whole 16-row steps
@@ -2389,7 +2389,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
           f.gamma[k] = params + L.g[tw][0]; f.beta[k] = params + L.be[tw][0];
           f.slab[k] = ws + W.slab[tw][0]; f.colpart[k] = ws + W.colpart[tw][0];
         }
-        f.x = x; f.mean = obs_mean; f.std = obs_std; f.clamp_lo = clamp_lo; f.clamp_hi = clamp_hi;
+        f.x = x; f.in = L.in_dim[0]; f.mean = obs_mean; f.std = obs_std; f.clamp_lo = clamp_lo; f.clamp_hi = clamp_hi;
         f.M = (int)mb; f.rows_per_block = first_fused_rows(mb);
         static const bool lds_ok = [] {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnbwd_wgrad0_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

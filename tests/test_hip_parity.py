@@ -73,6 +73,8 @@ NETS = {
     'full_relu': dict(obs=64, act=12, units=[512, 256, 128], norm=None, actf='ReLU', fixed=True),
     'full_lntanh': dict(obs=64, act=12, units=[512, 256, 128], actf='Tanh'),
     'mid_tanh': dict(obs=20, act=3, units=[256, 64], norm=None, actf='Tanh'),
+    # the observation width of DFlex Ant (37, padded to 40 by the host classes) in front of the DFlexAntPPO layers
+    'full_obs40': dict(obs=40, act=8, units=[512, 256, 128]),
 }
 
 
@@ -284,6 +286,7 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     # minibatches of 8192 rows and more take the weight gradients of whole-128 layers through the split-bf16 kernel; 8328 rows
     # end in a partial 16-row step
     ('full', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('full_obs40', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),   # first layer on fewer than 64 inputs (one-launch LayerNorm backward + weight gradient)
     ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
     ('odd_heads', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),

@@ -24,7 +24,7 @@ CASES = [('mid', 64, 8, 128, 'dreamerv3_normal'), ('full', 64, 8, 256, 'dreamerv
 # AB_BIG=1: batches above 8,192 rows instead (the per-layer kernel family; ragged row counts included)
 if os.environ.get('AB_BIG'):
     CASES = [('full', 1024, 32, 16384, 'dreamerv3_normal'), ('full', 2048, 32, 32768, 'dreamerv3_normal'), ('full_lnelu', 1024, 32, 16384, 'normal'),
-             ('full', 1024, 32, 12000, 'dreamerv3_normal'), ('full', 1024, 32, 9999, 'dreamerv3_normal'), ('mid', 1024, 32, 16384, 'dreamerv3_normal')]
+             ('full', 1024, 32, 12000, 'dreamerv3_normal'), ('full', 1024, 32, 9999, 'dreamerv3_normal'), ('mid', 1024, 32, 16384, 'dreamerv3_normal'), ('full_obs40', 1024, 32, 12000, 'dreamerv3_normal')]
 
 def grads_of(case):
     import test_hip_parity as T

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(g, one.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b, h.data(), N * 4, hipMemcpyHostToDevice));
     a.dh[k] = dh; a.xhat[k] = xh; a.rstd[k] = rs; a.gamma[k] = g; a.beta[k] = b; a.slab[k] = slab; a.colpart[k] = cp;
   }
-  a.x = x; a.mean = mean; a.std = std_; a.clamp_lo = -5.f; a.clamp_hi = 5.f; a.M = M; a.rows_per_block = rpb;
+  a.x = x; a.in = IN; a.mean = mean; a.std = std_; a.clamp_lo = -5.f; a.clamp_hi = 5.f; a.M = M; a.rows_per_block = rpb;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(lnbwd_wgrad0_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
