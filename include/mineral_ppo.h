@@ -257,6 +257,23 @@ int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_ppo_hp* hp, 
                        double beta2, double eps, double weight_decay, int32_t adamw, int64_t first_step,
                        float max_norm, float* gnorm_out, void* scratch, void* stream);
 
+/* mrl_ppo_mini_epoch for callers WITH a gradient all-reduce between backward and optimizer.step() (the multi_gpu branch of
+ * ppo.py:290-293): when the gradient of step i is complete in stream order, the library calls reduce(ctx, i, stream) on the
+ * calling thread.  The callback enqueues -- on `stream`, or ordered behind it and in front of whatever is enqueued on
+ * `stream` afterwards -- the in-place sum of `grads` over the ranks (it may also read metrics_out + i*MRL_NMETRIC there, which
+ * is complete at that point) and returns 0; any other value aborts the call with MRL_EHIP.  The optimizer step then runs on
+ * grads * grad_scale (1 / world size), taking the gradient norm from the reduced vector.  reduce == NULL: mrl_ppo_mini_epoch.
+ * With one rank and grad_scale == 1 the results are those of mrl_ppo_mini_epoch bit for bit. */
+typedef int (*mrl_reduce_fn)(void* ctx, int64_t step_index, void* stream);
+int mrl_ppo_mini_epoch_reduce(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb,
+                              int64_t n_minibatches, const mrl_rms* obs_rms, const float* batch_means,
+                              const float* batch_vars, double batch_count, float* obs_mean_f32, float* obs_std_f32,
+                              float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                              int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int32_t adamw, int64_t first_step,
+                              float max_norm, float* gnorm_out, void* scratch, void* stream, float grad_scale,
+                              mrl_reduce_fn reduce, void* ctx);
+
 /* Benchmark support, no counterpart in the reference: time the MFMA GEMM launches with HIP events on the stream
  * they are issued to.  mode 0 = off (default), 1 = every GEMM instantiation, 2 = only the instantiation that has
  * accumulated the most time so far (call after a mode-1 warm-up; with nothing timed since the last call the choice of the last

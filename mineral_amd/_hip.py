@@ -88,6 +88,8 @@ def make_critic_net(obs_dim, n_critics, units, ln_eps=1e-5, act_type='SiLU'):
 
 
 _P = C.c_void_p
+# int reduce(void* ctx, int64_t step_index, void* stream): the gradient all-reduce hook of mrl_ppo_mini_epoch_reduce
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 _SIGNATURES = {
     'mrl_last_error': (C.c_char_p, []),
     'mrl_version': (C.c_int, []),
@@ -117,6 +119,10 @@ _SIGNATURES = {
     'mrl_ppo_mini_epoch': (C.c_int, [C.POINTER(Net), _P, C.POINTER(PpoHp), C.POINTER(Rollout), C.c_int64, C.c_int64, C.POINTER(Rms), _P, _P,
                                      C.c_double, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_float, _P, _P, _P]),
+    'mrl_ppo_mini_epoch_reduce': (C.c_int, [C.POINTER(Net), _P, C.POINTER(PpoHp), C.POINTER(Rollout), C.c_int64, C.c_int64, C.POINTER(Rms), _P, _P,
+                                            C.c_double, _P, _P, C.c_float, C.c_float, _P, _P, _P, C.c_int64, _P, _P, C.c_double, C.c_double,
+                                            C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_float, _P, _P, _P, C.c_float, REDUCE_FN,
+                                            _P]),
     'mrl_nstep_emit': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int32, C.POINTER(Transitions), C.c_int64, C.c_int32, _P,
                                  C.POINTER(Transitions), _P]),
     'mrl_replay_write': (C.c_int, [C.POINTER(Transitions), C.c_int64, C.c_int64, C.POINTER(Transitions), C.c_int64, _P]),

@@ -160,6 +160,9 @@ class PPO(Agent):
 
         # --- Multi-GPU (ppo.py:115-123): no wrapper objects; see _sync_* below ---
         self._dist = None
+        # ranked runs take one library call per mini-epoch with a hook for the all-reduce (MRL_RANKED_CALLS=1: the four calls per
+        # minibatch instead -- merge, gradient, all-reduce, optimizer -- with the same results bit for bit)
+        self._one_call_ranked = os.environ.get('MRL_RANKED_CALLS', '0') != '1'
         if self.multi_gpu:   # also with a group of one rank: the collectives then run (through RCCL) on this rank's own data
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -330,7 +333,37 @@ class PPO(Agent):
                                                 _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s), 'mrl_ppo_mini_epoch')
                 self.optim_step += n_mb
                 k += n_mb
-            for i in range(n_mb if self._dist is not None else 0):
+            if self._dist is not None and self._one_call_ranked:
+                # ranked: the same call with a hook between backward and optimizer.step() for the one collective per step
+                # (ppo.py:292); on the last step of a mini-epoch the sum of the mini-epoch's KL values rides in the tail
+                # (the reference gathers its metrics every step, ppo.py:305-311)
+                failure = []
+
+                def _reduce(_ctx, i, _stream, k0=k0):
+                    try:
+                        if i == n_mb - 1:
+                            parallel.pack_scalar(self._grads_full[P:], self._metrics[k0:k0 + n_mb, 3].sum())
+                        parallel.average_gradients(self._grads_full, self._dist)
+                        return 0
+                    except BaseException as e:   # never unwind through the C frames: report and let the call fail
+                        failure.append(e)
+                        return 1
+                cb = _hip.REDUCE_FN(_reduce)
+                status = L.mrl_ppo_mini_epoch_reduce(net, _hip.ptr(flat), self.hp, buf.c, mb, n_mb, obs_rms,
+                                                     _hip.ptr(self._mb_mean) if obs_rms is not None else None,
+                                                     _hip.ptr(self._mb_var) if obs_rms is not None else None, count,
+                                                     _hip.ptr(self._obs_mean_f) if obs_rms is not None else None,
+                                                     _hip.ptr(self._obs_std_f) if obs_rms is not None else None, lo, hi,
+                                                     _hip.ptr(self.grads), _hip.ptr(self._metrics[k]), _hip.ptr(self._ws), self._ws.numel(),
+                                                     _hip.ptr(self.exp_avg), _hip.ptr(self.exp_avg_sq), self._optim_lr, self.betas[0],
+                                                     self.betas[1], self.adam_eps, self.weight_decay, adamw, self.optim_step + 1, max_norm,
+                                                     _hip.ptr(self._gnorm[k:]), _hip.ptr(self._adam_scratch), s, grad_scale, cb, None)
+                if failure:
+                    raise failure[0]
+                _hip.check(status, 'mrl_ppo_mini_epoch_reduce')
+                self.optim_step += n_mb
+                k += n_mb
+            for i in range(n_mb if (self._dist is not None and not self._one_call_ranked) else 0):
                 if self.normalize_input:
                     _hip.check(L.mrl_rms_merge(obs_rms, _hip.ptr(self._mb_mean[i]), _hip.ptr(self._mb_var[i]), count,
                                                _hip.ptr(self._obs_mean_f), _hip.ptr(self._obs_std_f), s), 'mrl_rms_merge')

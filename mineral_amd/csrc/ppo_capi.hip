@@ -2913,11 +2913,12 @@ extern "C" int mrl_ppo_step(const mrl_net* net, float* params, const mrl_ppo_hp*
                    stream, prenorm);
 }
 
-extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb, int64_t n_minibatches,
-                                  const mrl_rms* obs_rms, const float* batch_means, const float* batch_vars, double batch_count, float* obs_mean_f32,
-                                  float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
-                                  int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
-                                  double weight_decay, int32_t adamw, int64_t first_step, float max_norm, float* gnorm_out, void* scratch, void* stream) {
+static int mini_epoch_impl(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb, int64_t n_minibatches,
+                           const mrl_rms* obs_rms, const float* batch_means, const float* batch_vars, double batch_count, float* obs_mean_f32,
+                           float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                           int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, int32_t adamw, int64_t first_step, float max_norm, float* gnorm_out, void* scratch, void* stream,
+                           float grad_scale, mrl_reduce_fn reduce, void* ctx) {
   if (check_net(net) || check_buf(buf)) return MRL_EINVAL;
   if (n_minibatches < 1 || mb < 2 || mb * n_minibatches > buf->num_envs * (int64_t)buf->horizon)
     MRL_FAIL(MRL_EINVAL, "%lld minibatches of %lld rows do not fit the batch", (long long)n_minibatches, (long long)mb);
@@ -2980,15 +2981,41 @@ extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_p
     if (int rc = ppo_grad_impl(net, params, hp, buf, i * mb, mb, obs_mean_f32, obs_std_f32, clamp_lo, clamp_hi, grads, metrics_out + i * MRL_NMETRIC,
                                workspace, workspace_bytes, stream, &norm_ready, (obs_rms && first) ? &m0 : nullptr, !first))
       return rc;
-    const double* prenorm = norm_ready ? (const double*)((const float*)workspace + W.norm_part) : nullptr;
+    // the caller's all-reduce of the gradient (its norm partials, taken while this rank's gradient was written, no longer hold)
+    if (reduce) {
+      if (const int rc = reduce(ctx, i, stream)) MRL_FAIL(MRL_EHIP, "the gradient reduction callback failed at step %lld (%d)", (long long)i, rc);
+    }
+    const double* prenorm = (norm_ready && !reduce) ? (const double*)((const float*)workspace + W.norm_part) : nullptr;
     const bool more = (carry || carry_planes) && i + 1 < n_minibatches;
     tab.has_merge = (more && obs_rms) ? 1 : 0;
     if (tab.has_merge) tab.merge = merge_of(i + 1);
-    if (int rc = adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, first_step + i, max_norm, 1.0f,
+    if (int rc = adam_impl(params, grads, exp_avg, exp_avg_sq, L.total, lr, beta1, beta2, eps, weight_decay, adamw, first_step + i, max_norm, grad_scale,
                            gnorm_out ? gnorm_out + i : nullptr, scratch, stream, prenorm, more ? &tab : nullptr))
       return rc;
   }
   return MRL_OK;
+}
+
+extern "C" int mrl_ppo_mini_epoch(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb, int64_t n_minibatches,
+                                  const mrl_rms* obs_rms, const float* batch_means, const float* batch_vars, double batch_count, float* obs_mean_f32,
+                                  float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out, void* workspace,
+                                  int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                                  double weight_decay, int32_t adamw, int64_t first_step, float max_norm, float* gnorm_out, void* scratch, void* stream) {
+  return mini_epoch_impl(net, params, hp, buf, mb, n_minibatches, obs_rms, batch_means, batch_vars, batch_count, obs_mean_f32, obs_std_f32, clamp_lo,
+                         clamp_hi, grads, metrics_out, workspace, workspace_bytes, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, adamw,
+                         first_step, max_norm, gnorm_out, scratch, stream, 1.0f, nullptr, nullptr);
+}
+
+extern "C" int mrl_ppo_mini_epoch_reduce(const mrl_net* net, float* params, const mrl_ppo_hp* hp, const mrl_rollout* buf, int64_t mb, int64_t n_minibatches,
+                                         const mrl_rms* obs_rms, const float* batch_means, const float* batch_vars, double batch_count,
+                                         float* obs_mean_f32, float* obs_std_f32, float clamp_lo, float clamp_hi, float* grads, double* metrics_out,
+                                         void* workspace, int64_t workspace_bytes, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                                         double beta2, double eps, double weight_decay, int32_t adamw, int64_t first_step, float max_norm,
+                                         float* gnorm_out, void* scratch, void* stream, float grad_scale, mrl_reduce_fn reduce, void* ctx) {
+  if (!(grad_scale > 0.f)) MRL_FAIL(MRL_EINVAL, "grad_scale %g must be positive", (double)grad_scale);
+  return mini_epoch_impl(net, params, hp, buf, mb, n_minibatches, obs_rms, batch_means, batch_vars, batch_count, obs_mean_f32, obs_std_f32, clamp_lo,
+                         clamp_hi, grads, metrics_out, workspace, workspace_bytes, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, adamw,
+                         first_step, max_norm, gnorm_out, scratch, stream, grad_scale, reduce, ctx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

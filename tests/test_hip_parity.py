@@ -904,24 +904,27 @@ def test_torch_custom_operators_run_the_same_kernels(hip):
 def test_one_rank_rccl_group_matches_the_single_process_path(mb):
     """The same multi-rank code path over RCCL (backend 'nccl') with a one-rank group on this GPU: every collective the agent
     issues runs through RCCL on device tensors, and the parameters after an update must equal the single-process run's
-    bit for bit (global statistics of one rank are its local ones).  The single-process run takes the one-call mini-epoch, the
-    ranked run merge / gradient / all-reduce / optimizer calls per minibatch; 4096 rows run the chain kernels, 16384 the
-    per-layer split-bf16 kernels."""
+    bit for bit (global statistics of one rank are its local ones).  The single-process run takes the one-call mini-epoch; the
+    ranked run the same call with the all-reduce hook (mrl_ppo_mini_epoch_reduce), and with MRL_RANKED_CALLS=1 the merge /
+    gradient / all-reduce / optimizer calls per minibatch; 4096 rows run the chain kernels, 16384 the per-layer split-bf16
+    kernels."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra in ([], ['--force-dist']):
+    for extra, calls in (([], '0'), (['--force-dist'], '0'), (['--force-dist'], '1')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--num-envs', '1024', '--minibatch', str(mb),
                '--no-kernel-timing', '--no-cpu-baseline', '--no-secondary'] + extra
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), MRL_RANKED_CALLS=calls)
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]))
-    assert outs[1]['ranks_in_sync'] is True
-    assert outs[0]['param_checksum'] == outs[1]['param_checksum']
-    assert outs[0]['param_sha256'] == outs[1]['param_sha256']
+    for o in outs[1:]:
+        assert o['ranks_in_sync'] is True
+        assert outs[0]['param_checksum'] == o['param_checksum']
+        assert outs[0]['param_sha256'] == o['param_sha256']
+        assert o['collectives_per_update']['all_reduce'] == outs[1]['collectives_per_update']['all_reduce']
 
 
 @pytest.mark.gpu
