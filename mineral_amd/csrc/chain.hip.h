@@ -1153,13 +1153,10 @@ __device__ __forceinline__ void wgrad_small_task(const WgradSmallP& p, const WgD
     const int c = m0 + 4 * r16 + 2 * hf;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      cz[e] += __shfl_xor(cz[e], 16);
-      cz[e] += __shfl_xor(cz[e], 32);
+      cz[e] = add_xor32(add_xor16(cz[e]));
       if constexpr (COLS == 2) {
-        cg[e] += __shfl_xor(cg[e], 16);
-        cg[e] += __shfl_xor(cg[e], 32);
-        cb[e] += __shfl_xor(cb[e], 16);
-        cb[e] += __shfl_xor(cb[e], 32);
+        cg[e] = add_xor32(add_xor16(cg[e]));
+        cb[e] = add_xor32(add_xor16(cb[e]));
       }
     }
     if (g == 0 && c < d.u) {

@@ -212,22 +212,36 @@ __device__ __forceinline__ float halving_sum32(float (&v)[V], int l32) {
   return r;
 }
 
-// sum over the 32 lanes of a half-wave (all lanes of the half receive the total)
-__device__ __forceinline__ float half_sum32(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
-  return v;
+// Cross-lane sums on DPP adds and lane swaps instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32 (an LDS-crossbar round
+// trip of > 100 cycles per step).  The values added are those of the xor butterfly (v + v[lane ^ 1], ^ 2, ^ 4, ^ 8, ^ 16: after
+// every step the lanes of a group hold one common value, so "the lane mirrored inside the group" supplies the same addend as
+// "the lane ^ step"), so the results are bit-identical to it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {   // the DPP-selected lane's value; 0 in rows that ROW_MASK leaves out
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
+// sum over each group of 16 consecutive lanes (all lanes of the group receive the total)
 __device__ __forceinline__ float group_sum16(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += dpp_take<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_take<0x140, 0xf>(v);   // row_mirror
   return v;
 }
+// v + v[lane ^ 16]: v_permlane16_swap of (v, v) leaves {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}
+__device__ __forceinline__ float add_xor16(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+}
+// v + v[lane ^ 32]: v_permlane32_swap of (v, v) leaves {low half, low half} and {high half, high half}
+__device__ __forceinline__ float add_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+}
+// sum over the 32 lanes of a half-wave (all lanes of the half receive the total)
+__device__ __forceinline__ float half_sum32(float v) { return add_xor16(group_sum16(v)); }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LA, int LB, int EPI>
 struct GemmCfg {
@@ -782,7 +796,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           t0 += ea[im][in][r]; t1 += ea[im][in][r + 1]; t2 += ea[im][in][r + 2]; t3 += ea[im][in][r + 3];
         }
       float t = (t0 + t1) + (t2 + t3);
-      t += __shfl_xor(t, 32);
+      t = add_xor32(t);
       if (h == 0) partA[wn * BM + wm * TM * 32 + im * 32 + l32] = t;
     }
     MRL_KT(1003);
@@ -805,7 +819,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
         }
       float q = (q0 + q1) + (q2 + q3);
-      q += __shfl_xor(q, 32);
+      q = add_xor32(q);
       if (h == 0) partB[wn * BM + row] = q;
     }
     MRL_KT(1005);
@@ -916,8 +930,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     }
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      const float a = sg[in] + __shfl_xor(sg[in], 32);
-      const float b = sb[in] + __shfl_xor(sb[in], 32);
+      const float a = add_xor32(sg[in]);
+      const float b = add_xor32(sb[in]);
       if (h == 0) {
         cred[(wm * 3 + 0) * BN + colof(in)] = a;
         cred[(wm * 3 + 1) * BN + colof(in)] = b;
@@ -971,7 +985,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
     }
 #pragma unroll
     for (int in = 0; in < TN; ++in) {
-      float z = cz[in] + __shfl_xor(cz[in], 32);
+      float z = add_xor32(cz[in]);
       if (h == 0) cred[(wm * 3 + 2) * BN + colof(in)] = z;
     }
     __syncthreads();
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           cz += dz;
         }
       }
-      cz += __shfl_xor(cz, 32);
+      cz = add_xor32(cz);
       if (h == 0) cred[wm * BN + colof(in)] = cz;
     }
     __syncthreads();

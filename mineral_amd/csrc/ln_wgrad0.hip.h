@@ -49,10 +49,6 @@ struct LnWg0Args {
   int M, rows_per_block;    // rows_per_block a multiple of 16
 };
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_take(float v) {   // the DPP-selected lane's value; 0 in rows that ROW_MASK leaves out
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
 // sum over the 64 lanes of the wave, in every lane
 __device__ __forceinline__ float wave_total(float v) {
   v += dpp_take<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]

@@ -5,6 +5,7 @@
 #include "split_bf16.hip.h"
 #include "ln_wgrad0.hip.h"
 #include "chain.hip.h"
+#include "ppo_tail.hip.h"
 #include "wgrad_group.hip.h"
 
 #include <hip/hip_ext.h>
@@ -184,6 +185,17 @@ static bool first_fused(const mrl_net* net, const int* in_dim, int64_t rows) {
 }
 // rows per block of that launch: about 128 blocks per tower (one block per CU with two towers), whole 16-row steps
 static int first_fused_rows(int64_t rows) { return (int)std::max<int64_t>(64, cdiv(cdiv(rows, 128), 16) * 16); }
+
+// LayerNorm towers whose last layer has 128 outputs, on batches above MRL_SMALL_M rows: heads, losses, the heads' input gradient and
+// the last layer's LayerNorm backward are one launch (ppo_tail.hip.h), one block per 128 rows (the row blocks of the launches
+// it replaces, so the partial buffers keep their shapes).  MRL_PPO_TAIL=0 in the environment (read once) keeps the two launches.
+static bool ppo_tail_ok(const mrl_net* net, const ParamLayout& L, int64_t rows) {
+  static const bool on = [] { const char* e = getenv("MRL_PPO_TAIL"); return e ? atoi(e) != 0 : true; }();
+  const int nl = net->n_layers;
+  return on && rows > MRL_SMALL_M && nl >= 2 && net->units[nl - 1] == TAIL_U && net->act_dim <= 16 && L.head_rows[0] <= 32 && L.head_rows[1] <= 32 &&
+         (net->tower_kind == MRL_TOWER_LAYERNORM_SILU || net->tower_kind == MRL_TOWER_LAYERNORM_ELU) && !chain_ok(net, rows, 2) &&
+         fused_bwd_rows(TAIL_U, rows) == 128;
+}
 // 64 x 64 weight-gradient tiles of one tower (layers + head) and the row ranges they are split into: about 1,024 wave tasks
 // for two towers (one per SIMD: the launch keeps one block of four waves per CU), at least 64 rows each, whole multiples of 32 rows
 static int chain_wgrad_tiles(const mrl_net* net, const int* in_dim) {
@@ -2261,7 +2273,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
                               const float* obs_mean, const float* obs_std, float clamp_lo, float clamp_hi, int tw0, int towers, bool wgrad,
                               float* const* input_grad, hipStream_t s, bool planes_ready = false, hipStream_t wgrad_stream = nullptr,
                               hipEvent_t* wgrad_events = nullptr, const std::function<void(hipStream_t)>* beside_first = nullptr,
-                              bool* beside_first_done = nullptr) {
+                              bool* beside_first_done = nullptr, bool last_done = false) {
   const int nl = net->n_layers, last = nl - 1, U = net->units[last];
   if (chain_ok(net, mb, 2)) {
     // small batches: the whole dgrad chain in one launch, every weight gradient in a second one
@@ -2328,6 +2340,11 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
     planes = planes_ready ? reinterpret_cast<const unsigned short*>(ws + W.wplanes) : launch_split_params(L, W, ws, params, s);
   // ---- dgrad chain (each launch ends in the LayerNorm/SiLU backward of the layer below) --------------------------
   for (int l = last; l >= 0; --l) {
+    if (l == last && last_done) {   // dZ of the last layer came out of the caller's tail launch
+      flush_pending(false);
+      if (side_wgrad) wgrad_beside(l);
+      continue;
+    }
     GemmP p;
     memset(&p, 0, sizeof(p));
     const int u = net->units[l];
@@ -2629,6 +2646,22 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
     else if (net->tower_kind == TOWER_LAYERNORM_ELU) launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNELU>(p, dim3(hblocks, 1, towers), st);
     else launch_gemm<128, 32, 32, 4, 1, LAY_K, LAY_K, EPI_HEADS_TRAIN, PRO_LNSILU>(p, dim3(hblocks, 1, towers), st);
   };
+  // heads, losses, seeds and the last layer's dZ of towers [tw0, tw0 + towers) in one launch (ppo_tail_ok)
+  auto launch_tail = [&](int tw0, int towers, hipStream_t st) {
+    PpoTailP tp;
+    memset(&tp, 0, sizeof(tp));
+    fill_heads(tp.h);
+    for (int tw = 0; tw < 2; ++tw) {
+      tp.xhat[tw] = ws + W.xhat[tw][last]; tp.rstd[tw] = ws + W.rstd[tw][last];
+      tp.gamma[tw] = params + L.g[tw][last]; tp.beta[tw] = params + L.be[tw][last];
+      tp.Wh[tw] = params + L.Wh[tw]; tp.bh[tw] = params + L.bh[tw]; tp.head_n[tw] = L.head_rows[tw];
+      tp.dz[tw] = ws + W.dz[tw][last]; tp.colpart[tw] = ws + W.colpart[tw][last];
+    }
+    tp.M = (int)mb; tp.rows_per_block = 128; tp.tw0 = tw0;
+    MRL_PROF_STREAM("ppo_tail_kernel", st);
+    if (net->tower_kind == TOWER_LAYERNORM_ELU) hipLaunchKernelGGL(ppo_tail_kernel<true>, dim3(hblocks, towers), dim3(64 * TAIL_WAVES), 0, st, tp);
+    else hipLaunchKernelGGL(ppo_tail_kernel<false>, dim3(hblocks, towers), dim3(64 * TAIL_WAVES), 0, st, tp);
+  };
   // the reduction of the heads' metric partials: any-order behind the first dgrad launch of the backward chain when that is
   // on (launch_towers_bwd), otherwise an ordinary launch at the end
   auto launch_metrics = [&](hipStream_t st) {
@@ -2685,10 +2718,12 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
     for (int tw = 0; tw < 2; ++tw) {
       hipStream_t st = tw == 0 ? s : ss->s;
       launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, st, wpl);
-      launch_heads(tw, 1, st);
+      const bool tail = ppo_tail_ok(net, L, mb);
+      if (tail) launch_tail(tw, 1, st); else launch_heads(tw, 1, st);
       // weight-gradient launches of each chain on a stream of their own (MRL_WGRAD_STREAMS=0 keeps them in the chain)
       static const int wside = [] { const char* e = getenv("MRL_WGRAD_STREAMS"); return e ? atoi(e) : 1; }();
-      launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, true, nullptr, st, planes, wside ? ss->w[tw] : nullptr, ss->wev[tw]);
+      launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, tw, 1, true, nullptr, st, planes, wside ? ss->w[tw] : nullptr, ss->wev[tw],
+                        nullptr, nullptr, tail);
       if (wside && (hipEventRecord(ss->wjoin[tw], ss->w[tw]) != hipSuccess || hipStreamWaitEvent(st, ss->wjoin[tw], 0) != hipSuccess))
         MRL_FAIL(MRL_EHIP, "join of the weight-gradient stream failed");
       launch_grad_reduce(net, L, W, ws, grads, tw, 1, hblocks, st);
@@ -2696,9 +2731,10 @@ static int ppo_grad_impl(const mrl_net* net, const float* params, const mrl_ppo_
     if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(s, ss->join, 0) != hipSuccess) MRL_FAIL(MRL_EHIP, "join of the tower streams failed");
   } else {
     launch_towers_fwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, s, wpl, true);
-    launch_heads(0, 2, s);
+    const bool tail = ppo_tail_ok(net, L, mb);
+    if (tail) launch_tail(0, 2, s); else launch_heads(0, 2, s);
     launch_towers_bwd(net, L, W, ws, params, x, mb, obs_mean, obs_std, clamp_lo, clamp_hi, 0, 2, true, nullptr, s, planes || ch_b, nullptr, nullptr, &metrics_hook,
-                      &metrics_done);
+                      &metrics_done, tail);
     launch_grad_reduce(net, L, W, ws, grads, 0, 2, hblocks, s, true, nullptr, norm_ready);
   }
   if (!metrics_done) launch_metrics(s);
