@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -Xclang -target-feature -Xclang -packed-fp32-ops -Wno-unused-value
 SRC = mineral_amd/csrc/ppo_capi.hip mineral_amd/csrc/replay.hip
-HDR = mineral_amd/csrc/gemm.hip.h mineral_amd/csrc/chain.hip.h mineral_amd/csrc/wgrad_group.hip.h mineral_amd/csrc/split_bf16.hip.h mineral_amd/csrc/ln_wgrad0.hip.h mineral_amd/csrc/ppo_tail.hip.h mineral_amd/csrc/sac_capi.hip.inc mineral_amd/csrc/shac_capi.hip.inc include/mineral_ppo.h include/mineral_replay.h include/mineral_sac.h include/mineral_shac.h
+HDR = mineral_amd/csrc/gemm.hip.h mineral_amd/csrc/chain.hip.h mineral_amd/csrc/wgrad_group.hip.h mineral_amd/csrc/split_bf16.hip.h mineral_amd/csrc/ln_wgrad0.hip.h mineral_amd/csrc/ln_fwd0.hip.h mineral_amd/csrc/ppo_tail.hip.h mineral_amd/csrc/sac_capi.hip.inc mineral_amd/csrc/shac_capi.hip.inc include/mineral_ppo.h include/mineral_replay.h include/mineral_sac.h include/mineral_shac.h
 LIB = mineral_amd/libmineral_ppo.so
 
 all: $(LIB)

@@ -4,6 +4,7 @@
 #include "gemm.hip.h"
 #include "split_bf16.hip.h"
 #include "ln_wgrad0.hip.h"
+#include "ln_fwd0.hip.h"
 #include "chain.hip.h"
 #include "ppo_tail.hip.h"
 #include "wgrad_group.hip.h"
@@ -891,6 +892,8 @@ static void launch_chain_fwd(const mrl_net* net, const ParamLayout& L, const Wor
   MRL_CHAIN_LAUNCH(chain_fwd_kernel, net->tower_kind, grid, lds, s, p);
 }
 
+// MRL_FWD0=0 in the environment (read once): the first layer's forward through gemm_kernel<64,512> (A/B runs)
+static bool fwd0_on() { static const bool on = [] { const char* e = getenv("MRL_FWD0"); return e ? atoi(e) != 0 : true; }(); return on; }
 static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Workspace& W, float* ws, const float* params,
                               const float* x, int64_t rows, const float* obs_mean, const float* obs_std, float lo, float hi,
                               int tw0, int towers, hipStream_t s, const unsigned short* planes = nullptr, bool blocked_ready = false) {
@@ -929,6 +932,27 @@ static void launch_towers_fwd(const mrl_net* net, const ParamLayout& L, const Wo
     } else if (l > 0) {
       if (lnfwd_split_eligible(u, rows, in)) launch_lnfwd_split<PRO_LNSILU>(u, p, towers, s);
       else MRL_DISPATCH_ROWTILE(u, LAY_K, LAY_K, 32, EPI_LNFWD, PRO_LNSILU, p, towers, s);
+    }
+    else if (u == LNF0_N && rows > MRL_SMALL_M && in <= LNF0_K && in % 4 == 0 && fwd0_on()) {
+      // first layer of 512 outputs on at most 64 inputs: the weights stay in registers, a block walks a row range (ln_fwd0.hip.h)
+      LnFwd0Args f;
+      memset(&f, 0, sizeof(f));
+      f.x = x; f.in = in; f.mean = obs_mean; f.std = obs_std; f.clamp_lo = lo; f.clamp_hi = hi;
+      for (int t = 0; t < towers; ++t) {
+        const int tw = tw0 + t;
+        f.W[tw] = params + L.W[tw][0]; f.bias[tw] = params + L.b[tw][0];
+        f.xhat[tw] = ws + W.xhat[tw][0]; f.rstd[tw] = ws + W.rstd[tw][0];
+      }
+      f.M = (int)rows; f.Mpad = (int)(cdiv(rows, 128) * 128);
+      f.rows_per_block = (int)std::max<int64_t>(LNF0_ROWS, cdiv(cdiv(f.Mpad, 256 / towers), LNF0_ROWS) * LNF0_ROWS);
+      f.tw0 = tw0; f.eps = net->ln_eps;
+      static const bool lds_ok = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnfwd0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)lds_ok;
+      MRL_PROF_STREAM("lnfwd0_kernel", s);
+      hipLaunchKernelGGL(lnfwd0_kernel, dim3((unsigned)cdiv(f.Mpad, f.rows_per_block), towers), dim3(LNF0_THREADS), LNF0_LDS, s, f);
     }
     else if (u == 512 && rows > MRL_SMALL_M && in % 16 == 0) {     // first layer of 512 outputs: split-bf16 main loop, single stage
       const dim3 grid((unsigned)cdiv(p.M, 64), 1, towers);
