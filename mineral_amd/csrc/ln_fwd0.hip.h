@@ -21,6 +21,13 @@
 
 namespace mrl {
 
+#ifdef LNF0_TRACE
+__device__ long long g_lnf0_trace[2][64];   // [role][slot] cycle stamps of block 0 (probe builds only)
+#define LNF0_STAMP(role, slot) do { if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4) && (slot) < 64) g_lnf0_trace[role][slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LNF0_STAMP(role, slot) do { } while (0)
+#endif
+
 struct LnFwd0Args {
   const float* x;           // [rows][in]
   int in;                   // inputs per row: a multiple of 4, at most 64
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(LNF0_THREADS, 1) void lnfwd0_kernel(const LnFwd0Arg
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int64_t row = min(r0 + st * R + rb + 16 * i, a.M - 1);      // rows past the data repeat the last row: finite padding
-        if (in_b) ob[i] = *reinterpret_cast<const f32x4*>(xin + row * a.in + 4 * cb);
+        ob[i] = *reinterpret_cast<const f32x4*>(xin + row * a.in + (in_b ? 4 * cb : 0));   // chunks past the width are zeroed when staged
       }
     };
     auto stage_in = [&](int st) __attribute__((always_inline)) {
@@ -100,54 +107,94 @@ __global__ __launch_bounds__(LNF0_THREADS, 1) void lnfwd0_kernel(const LnFwd0Arg
         *reinterpret_cast<u32x2*>(q + 2 * R * XP) = l;
       }
     };
-    // LayerNorm of the z stage of step st: wave w owns rows 8 w .. +7
+    // LayerNorm of the z stage of step st: wave w owns rows 8 w .. +7.  The eight rows advance together, phase by phase,
+    // in straight-line code: one row's chain (LDS read, two wave totals, store) is some 800 cycles of latency with
+    // nothing else on the SIMD to hide it, eight interleaved chains cost little more than one.  Every row of the block
+    // exists in the padded activation tensor (the block's row count is a multiple of the step), so nothing is guarded.
     auto layernorm = [&](int st) __attribute__((always_inline)) {
       const float* zb = reinterpret_cast<const float*>(zst(st & 1));
       const float invn = 1.0f / (float)N;
+      const int lr0 = 8 * wave, row0 = r0 + st * R + lr0;
+      f32x4 z[8][2];
+      float s[8], v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) z[i][c] = *reinterpret_cast<const f32x4*>(zb + (lr0 + i) * ZP + 4 * lane + 256 * c);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int lr = 8 * wave + i, row = r0 + st * R + lr;
-        f32x4 z[2];
-        float s = 0.f;
+        s[i] = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          z[c] = *reinterpret_cast<const f32x4*>(zb + lr * ZP + 4 * lane + 256 * c) + b4[c];
-          s += (z[c][0] + z[c][1]) + (z[c][2] + z[c][3]);
+          z[i][c] += b4[c];
+          s[i] += (z[i][c][0] + z[i][c][1]) + (z[i][c][2] + z[i][c][3]);
         }
-        const float mean = ((LNF0_ABL & 2) ? s : wave_total(s)) * invn;
-        float v = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = ((LNF0_ABL & 2) ? s[i] : wave_total(s[i])) * invn;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            z[c][e] -= mean;
-            v += z[c][e] * z[c][e];
+            z[i][c][e] -= s[i];
+            v[i] += z[i][c][e] * z[i][c][e];
           }
-        const float rstd = (LNF0_ABL & 2) ? v : 1.0f / sqrtf(wave_total(v) * invn + a.eps);
-        if (row < r1 && (!(LNF0_ABL & 4) || rstd == 1.2345e-30f)) {
+      }
 #pragma unroll
-          for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(xo + (int64_t)row * N + 4 * lane + 256 * c) = z[c] * rstd;
-          if (lane == 0) rso[row] = rstd;
-        }
+      for (int i = 0; i < 8; ++i) v[i] = (LNF0_ABL & 2) ? v[i] : wave_total(v[i]);
+      // the totals are wave-uniform: lane i takes row i's, one square root and one division serve the eight rows
+      // (the exact fp32 sequences are some 25 instructions), and the rows read their factor back as a scalar
+      float mine = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm("v_writelane_b32 %0, %1, %2" : "+v"(mine) : "s"(v[i]), "n"(i));
+      if (!(LNF0_ABL & 2)) mine = 1.0f / sqrtf(mine * invn + a.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), i));
+      if (!(LNF0_ABL & 4) || mine == 1.2345e-30f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(xo + (int64_t)(row0 + i) * N + 4 * lane + 256 * c) = z[i][c] * v[i];
+        if (lane < 8) rso[row0 + lane] = mine;
       }
     };
+    // The loop body is the same on every pass (the loads and the staging past the last step repeat the last step into
+    // a stage nobody reads) and uses the prefetched inputs after the LayerNorm stores of the same pass: the wait for
+    // the inputs can then be "all but the stores issued since".  With a conditional part, or with the use ahead of the
+    // stores, the compiler has to wait for every outstanding store, and their round trip to memory is paid once a step.
+    asm volatile("" :: "v"(b4[0]), "v"(b4[1]));         // the bias has arrived before the loop, not inside it
+    LNF0_STAMP(0, 0);
     load_in(0);
     stage_in(0);
-    if (nsteps > 1) load_in(1);
+    load_in(min(1, nsteps - 1));
+    LNF0_STAMP(0, 1);
     __syncthreads();                                    // inputs of step 0 are staged
-    for (int st = 0; st < nsteps; ++st) {
+    LNF0_STAMP(0, 2);
+    stage_in(1);                                        // the matrix waves multiply step 0
+    load_in(min(2, nsteps - 1));
+    LNF0_STAMP(0, 3);
+    LNF0_STAMP(0, 4);
+    __syncthreads();
+    LNF0_STAMP(0, 5);
+    for (int st = 1; st < nsteps; ++st) {
       // the matrix waves multiply step st
-      if (st + 1 < nsteps) {
-        stage_in(st + 1);
-        if (st + 2 < nsteps) load_in(st + 2);
-      }
-      if (st > 0) layernorm(st - 1);
+      layernorm(st - 1);
+      LNF0_STAMP(0, 3 + 3 * st);
+      stage_in(st + 1);                                 // after the stores: the wait for the inputs can then count them
+      load_in(min(st + 2, nsteps - 1));
+      LNF0_STAMP(0, 4 + 3 * st);
       __syncthreads();                                  // z of step st and the inputs of step st + 1 are complete
+      LNF0_STAMP(0, 5 + 3 * st);
     }
     layernorm(nsteps - 1);
+    LNF0_STAMP(0, 3 + 3 * nsteps);
   } else {
     // ================= matrix waves =================
     const int mw = wave - 4, l32 = lane & 31, hh = lane >> 5;
+    LNF0_STAMP(1, 0);
     const float* __restrict__ Wg = a.W[tw];
     // the planes of W rows 64 mw + 32 i + l32, k = 16 ks + 8 hh .. + 7: [tile i][k step][plane]
     bf16x8 fw[2][4][3];
@@ -167,7 +214,9 @@ __global__ __launch_bounds__(LNF0_THREADS, 1) void lnfwd0_kernel(const LnFwd0Arg
         fw[i][ks][1] = __builtin_bit_cast(bf16x8, u32x4{m0[0], m0[1], m1[0], m1[1]});
         fw[i][ks][2] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
       }
+    LNF0_STAMP(1, 1);
     __syncthreads();                                    // inputs of step 0 are staged
+    LNF0_STAMP(1, 2);
     for (int st = 0; st < nsteps; ++st) {
       const char* xb = xst(st & 1);
       float* zb = reinterpret_cast<float*>(zst(st & 1));
@@ -190,6 +239,7 @@ __global__ __launch_bounds__(LNF0_THREADS, 1) void lnfwd0_kernel(const LnFwd0Arg
             else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i][ks][TW[term]], fx[TX[term]], acc[i], 0, 0, 0);
           }
       }
+      LNF0_STAMP(1, 3 + 3 * st);
       // acc[i][r] = z[batch row l32][column 64 mw + 32 i + (r & 3) + 8 (r >> 2) + 4 hh]: runs of four columns
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -198,7 +248,9 @@ __global__ __launch_bounds__(LNF0_THREADS, 1) void lnfwd0_kernel(const LnFwd0Arg
           const f32x4 v = {acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]};
           if (!(LNF0_ABL & 8) || v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(zb + l32 * ZP + 64 * mw + 32 * i + 8 * j + 4 * hh) = v;
         }
+      LNF0_STAMP(1, 4 + 3 * st);
       __syncthreads();                                  // z of step st is complete; the row waves may refill the other stages
+      LNF0_STAMP(1, 5 + 3 * st);
     }
   }
 }

@@ -51,6 +51,16 @@ int main(int argc, char** argv) {
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = 1e3 * ms / reps, bytes = (double)towers * M * (N + IN) * 4;
+#ifdef LNF0_TRACE
+  long long tr[2][64];
+  CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_lnf0_trace), sizeof(tr)));
+  const char* names[2] = {"row wave 0", "matrix wave 4"};
+  for (int r = 0; r < 2; ++r) {
+    printf("%s (cycles since its first stamp): start, prologue done, first barrier passed | per step: work A done, work B done, barrier passed\n  ", names[r]);
+    for (int k = 0; k < 3 + 3 * 8 + 1; ++k) printf("%lld%s", tr[r][k] ? tr[r][k] - tr[r][0] : -1, (k == 2 || (k > 2 && (k - 2) % 3 == 0)) ? " | " : " ");
+    printf("\n");
+  }
+#endif
   printf("LNF0_ABL=%d rows %d blocks %d x %d (%d rows each): %.1f us per launch, %.2f TB/s\n", LNF0_ABL, M, nblk, towers, a.rows_per_block, us, bytes / us * 1e-6);
   return 0;
 }
