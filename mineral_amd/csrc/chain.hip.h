@@ -786,7 +786,9 @@ __device__ __forceinline__ void chain_heads_train(const HeadsP& hp, int tw, int 
     const float osg = jv ? hp.sigma[(int64_t)rowc * A + j] : 1.f;
     const float oldnl = hp.old_neglogp[rowc], adv = hp.adv[rowc];
     const float o = T[lr * CH_TS + j];
-    const float ls = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : T[lr * CH_TS + ((A + j) & 31)];
+    // (two separate loads: a select between the parameter's address and the LDS tile's would become one flat load)
+    const float ls_fixed = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : 0.f;
+    const float ls = hp.fixed_logstd ? ls_fixed : T[lr * CH_TS + ((A + j) & 31)];
     float mu, sg = 0.f, sigma;
     if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
       mu = ftanh(o);

@@ -1107,13 +1107,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, gemm_min_waves(BM, BN, EPI)) void g
           in_mu[it] = in_sg[it] = in_nl[it] = in_adv[it] = 0.f;
         }
       }
+      // read once: a select between the parameter's address and the LDS tile's inside the loop would be a flat load
+      // that waits for every outstanding store of the wave on each pass
+      const float ls_fixed = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : 0.f;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 4 + g;
         const int row = wrow0 + lr;
         const bool rv = row < p.M;
         const float o = T[lr * TS + j];
-        const float ls = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : T[lr * TS + ((A + j) & 31)];
+        const float ls = hp.fixed_logstd ? ls_fixed : T[lr * TS + ((A + j) & 31)];
         float mu, sg = 0.f, sigma;
         if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
           mu = ftanh(o);

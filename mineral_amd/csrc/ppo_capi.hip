@@ -1694,17 +1694,19 @@ __global__ __launch_bounds__(256) void reduce_flat_kernel(const FlatTable tab, f
     const FlatDesc d = s_d[lo];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c >= d.c0 && c < d.c1) {
+      // the pointer comes out of the LDS copy of the table: say that it points to global memory, or every load is a flat one
+      typedef const __attribute__((address_space(1))) f32x4* gptr;
       const float* src = d.src + 4 * (int64_t)(c - d.c0);
       const int ns = d.nslabs;
       int k = 0;
       for (; k + 8 <= ns; k += 8) {
         f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + u) * d.stride);
+        for (int u = 0; u < 8; ++u) v[u] = *(gptr)(src + (int64_t)(k + u) * d.stride);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
       }
-      for (; k < ns; ++k) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)k * d.stride);
+      for (; k < ns; ++k) acc += *(gptr)(src + (int64_t)k * d.stride);
     }
     *reinterpret_cast<f32x4*>(grads + 4 * (int64_t)c) = acc;
     sq = norm_chunk(sq, acc);

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, 2) void ppo_tail_kernel(const PpoT
     wave_sync();
   };
   float hb = 0.f;                                       // lanes < 32: column sum of the seeds (head bias gradient)
+  // a state-independent log-std is read once: selecting between the parameter's address and the LDS tile's inside the
+  // loop makes the access a flat load, which waits for every outstanding store of the wave on each of the four passes
+  const float fixed_ls = (hp.fixed_logstd && tw == 0) ? hp.fixed_logstd[r < A ? r : 0] : 0.f;
   double macc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   auto fexp = [](float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); };
   auto flog = [](float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); };
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES, 2) void ppo_tail_kernel(const PpoT
         const bool lrv = lrow < r1;
         const float a = in_a[pass], omu = in_mu[pass], osg = in_sg[pass], oldnl = in_nl[pass], adv = in_adv[pass];
         const float o = Tw[lr * TAIL_TS + j];
-        const float ls = hp.fixed_logstd ? hp.fixed_logstd[jv ? j : 0] : Tw[lr * TAIL_TS + ((A + j) & 31)];
+        const float ls = hp.fixed_logstd ? fixed_ls : Tw[lr * TAIL_TS + ((A + j) & 31)];
         float mu, sg = 0.f, sigma;
         if (hp.dist_type == DIST_DREAMERV3) {      // mineral/nets/dist.py:42-47
           mu = ftanh(o);
