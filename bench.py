@@ -297,12 +297,14 @@ def main():
                     hbm = []
                     for row in kernel_table:
                         nm = row['name'].split(' + ')[0]
-                        if not any(k in nm for k in ('gae_kernel', 'gae_normalize', 'moments_partial', 'rollout_write', 'ln_bwd', 'lnbwd_wgrad0', 'ppo_tail', 'reduce_slabs',
+                        if not any(k in nm for k in ('gae_kernel', 'gae_normalize', 'moments_partial', 'rollout_write', 'ln_bwd', 'lnbwd_wgrad0', 'lnfwd0', 'ppo_tail', 'reduce_slabs',
                                                      'reduce_flat', 'gradnorm', 'adam')):
                             continue
                         by = measured_traffic(nm if 'ln_bwd' in nm else nm.split('<')[0])
                         if by is None and 'lnbwd_wgrad0' in nm:
                             by = measured_traffic('mrl::lnbwd_wgrad0_kernel<64, false>')
+                        if by is None and 'lnfwd0' in nm:
+                            by = measured_traffic('mrl::lnfwd0_kernel')
                         if by is None and 'ppo_tail' in nm:
                             by = measured_traffic('mrl::ppo_tail_kernel<false>')
                         if by is None and nm == 'moments_partial_kernel':
