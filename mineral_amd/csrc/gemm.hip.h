@@ -240,6 +240,17 @@ __device__ __forceinline__ float add_xor32(float v) {
   const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
 }
+// Sum over the wave with the addends of the descending xor butterfly (v + v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1), bit-identical
+// to it: after the ^ 32 and ^ 16 steps the four rows of 16 lanes are equal, and a rotation of a row by 8, 4, 2, 1 lanes then
+// supplies the value the xor partner holds (after the step of width w the row has period w).
+__device__ __forceinline__ float wave_sum_desc(float v) {
+  v = add_xor16(add_xor32(v));
+  v += dpp_take<0x128, 0xf>(v);   // row_ror:8
+  v += dpp_take<0x124, 0xf>(v);   // row_ror:4
+  v += dpp_take<0x122, 0xf>(v);   // row_ror:2
+  v += dpp_take<0x121, 0xf>(v);   // row_ror:1
+  return v;
+}
 // sum over the 32 lanes of a half-wave (all lanes of the half receive the total)
 __device__ __forceinline__ float half_sum32(float v) { return add_xor16(group_sum16(v)); }
 

@@ -1506,11 +1506,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
         s1 += dxh;
         s2 += dxh * x[c][e];
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
-    }
+    s1 = mrl::wave_sum_desc(s1);
+    s2 = mrl::wave_sum_desc(s2);
     const float m1 = s1 * invn, m2 = s2 * invn;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
