@@ -61,6 +61,9 @@ NETS = {
     'elu_wide': dict(obs=20, act=3, units=[256, 64], norm=None, actf='ELU', fixed=True),
     'elu_head': dict(obs=64, act=12, units=[512, 128], norm=None, actf='ELU', fixed=False),
     'ln_fixed': dict(obs=64, act=12, units=[128, 64], fixed=True),
+    # the state-independent log-std on batches above 8192 rows: in the one-launch tail (128-wide last layer) and in the heads epilogue
+    'full_fixed': dict(obs=64, act=12, units=[512, 256, 128], fixed=True),
+    'ln_fixed_wide': dict(obs=64, act=12, units=[256, 64], fixed=True),
     'obs128': dict(obs=128, act=12, units=[128, 128]),
     'odd_heads': dict(obs=64, act=3, units=[256, 128]),     # 6-row heads: the tensors behind them start on odd offsets
     # LayerNorm + ELU towers (mlp_kwargs of DFlexAntSHAC.yaml / DFlexAntBPTT.yaml) in the PPO ActorCritic
@@ -288,6 +291,8 @@ def _fill_training_buffer(spec, buf, N, T, seed=0):
     ('full', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     ('full_obs40', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),   # first layer on fewer than 64 inputs (one-launch LayerNorm backward + weight gradient)
     ('elu_head', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
+    ('full_fixed', 1041, 8, 8328, 'normal', 0, 'bound'),
+    ('ln_fixed_wide', 1041, 8, 8328, 'normal', 1, 'reg'),
     ('obs128', 1024, 8, 8192, 'normal', 0, 'bound'),
     ('odd_heads', 1041, 8, 8328, 'dreamerv3_normal', 0, 'bound'),
     # no norm + SiLU, LayerNorm / no norm + ReLU, LayerNorm / no norm + Tanh: small batches and batches above 8192 rows
