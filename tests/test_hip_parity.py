@@ -188,7 +188,9 @@ def test_batch_moments_groups(hip):
                                        ('elu_head', 77, 'dreamerv3_normal'), ('ln_fixed', 64, 'normal'),
                                        ('mid_lnelu', 16, 'dreamerv3_normal'), ('full_lnelu', 300, 'normal'),
                                        ('mid_silu', 70, 'dreamerv3_normal'), ('full_relu', 300, 'normal'), ('full_lntanh', 9000, 'dreamerv3_normal'),
-                                       ('mid_tanh', 33, 'normal')])
+                                       ('mid_tanh', 33, 'normal'),
+                                       # above 8192 rows: the stationary-weight first-layer forward, whole and ragged row counts, 64 and 40 inputs
+                                       ('full', 8448, 'dreamerv3_normal'), ('full_obs40', 8333, 'normal')])
 def test_policy_act(hip, golden, net, N, dist):
     from mineral_amd.common.normalizers import RunningMeanStd
     spec = NETS[net]
