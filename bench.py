@@ -95,9 +95,19 @@ def measured_traffic(kernel):
     path = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f)['kernels'][kernel]['hbm_bytes']
+            kernels = json.load(f)['kernels']
     except (OSError, KeyError, ValueError):
         return None
+    if kernel in kernels:
+        return kernels[kernel]['hbm_bytes']
+    # a timing class may cover several instantiations (dgrad_split_kernel<true>: the launches with ordinary and with
+    # non-temporal output stores, <true, false> and <true, true>): the launch-weighted mean of those on file
+    if kernel.endswith('>'):
+        fam = [v for k, v in kernels.items() if k.startswith(kernel[:-1] + ',')]
+        n = sum(v['launches'] for v in fam)
+        if n:
+            return sum(v['hbm_bytes'] * v['launches'] for v in fam) / n
+    return None
 
 
 def main():

@@ -85,6 +85,7 @@ struct GemmP {
   int ksplit;                  // reduction rows per split
   int m_tiles, n_tiles;        // tile grid of the output
   int n_groups, group_mode;    // group_mode 0: group = row tile (dgrad), 1: group = split (wgrad)
+  int nt_hint;                 // host side only (launch_dgrad_split): 1 the streaming LayerNorm backward reads the output next, 2 the fused first-layer kernel
   // EPI_LNFWD: out = xhat [M][N], rstd [M], bias [N]
   // EPI_LNBWD: out = dz [M][N]; xhat/rstd/gamma/beta of the layer being differentiated; colpart slab
   // EPI_SLAB : out = slab [n_split][M][N]

@@ -643,7 +643,12 @@ static void launch_dgrad_split(const GemmP& p, dim3 grid, hipStream_t s) {
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
   }
-  if (planes) hipLaunchKernelGGL(dgrad_split_kernel<true>, grid, dim3(256), 0, s, p);
+  // MRL_NT in the environment (read once; A/B runs): bit 0 non-temporal output stores when the streaming LayerNorm backward reads
+  // the output next (default on), bit 1 also when the fused first-layer kernel does (default off: slower)
+  static const int nt_mask = [] { const char* e = getenv("MRL_NT"); return e ? atoi(e) : 1; }();
+  const bool nt = p.nt_hint == 1 ? (nt_mask & 1) != 0 : p.nt_hint == 2 ? (nt_mask & 2) != 0 : false;
+  if (planes && nt) hipLaunchKernelGGL((dgrad_split_kernel<true, true>), grid, dim3(256), 0, s, p);
+  else if (planes) hipLaunchKernelGGL(dgrad_split_kernel<true>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(dgrad_split_kernel<false>, grid, dim3(256), 0, s, p);
   if (timed) {
     (void)hipEventRecord(e1, s);
@@ -2415,6 +2420,7 @@ static void launch_towers_bwd(const mrl_net* net, const ParamLayout& L, const Wo
       } else {
         p.m_tiles = (int)cdiv(mb, 128); p.n_groups = p.m_tiles;
         const dim3 grid(slab_grid(p.n_groups, p.n_tiles), 1, towers);
+        p.nt_hint = (l == 0 && wgrad && first_fused(net, L.in_dim, mb)) ? 2 : 1;   // who reads the output next (launch_dgrad_split)
         if (l != last && kdim % 16 == 0) launch_dgrad_split(p, grid, s);   // A = dZ of the layer above, all K columns valid
         else launch_gemm<128, 128, 16, 2, 2, LAY_K, LAY_R, EPI_SLAB, PRO_NONE>(p, grid, s);
       }

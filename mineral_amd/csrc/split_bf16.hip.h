@@ -55,6 +55,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base) {
 // planes then take a 192-byte row pitch, with which four consecutive rows still cover all banks).
 // BMT: output rows per tile, 128 (2 x 2 waves) or 256 (4 x 2 waves, 512 threads: a tile of the layer input is then transformed
 // and split once for 256 output rows instead of once per 128, which is where most of this kernel's VALU work goes).
+#ifndef MRL_SLAB_NT
+#define MRL_SLAB_NT 1     // 0: ordinary stores for the weight-gradient slabs (A/B builds)
+#endif
 #ifndef MRL_ABLATE_WGRAD
 #define MRL_ABLATE_WGRAD 0   // diagnostic builds only: bit 0 no slab stores, 1 no prologue / split, 3 one step
 #endif
@@ -269,7 +272,14 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (!(WABL & 1) || acc[i][jn][r] == 1.2345e-30f) out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col] = acc[i][jn][r];
+        if (!(WABL & 1) || acc[i][jn][r] == 1.2345e-30f) {
+          // The slabs are read once, by the slab reduction at the end of the step, after several hundred MB of other traffic:
+          // non-temporal stores keep them from pushing the operands of the launches in between out of the caches (update
+          // 208.7 -> 205.9 ms on one box; the reduction itself 28.2 -> 29.5 us).  A run-time choice between the two kinds of
+          // store is folded into one ordinary store by the compiler, hence the build-time switch.
+          if constexpr (MRL_SLAB_NT) __builtin_nontemporal_store(acc[i][jn][r], &out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col]);
+          else out[(int64_t)row * p.ldo + n0 + wn * 32 * TN + jn * 32 + col] = acc[i][jn][r];
+        }
       }
 }
 
@@ -277,10 +287,13 @@ __global__ __launch_bounds__(BMT * 2, 2) void wgrad_split_kernel(const GemmP p) 
 // row) and B = that layer's weights ([K][N]).  K must be a multiple of 16; rows past M are computed from clamped loads and
 // not stored.
 // WPL: the weights come from planes split beforehand (GemmP::Bpl) and go to LDS as they are.
+// NT: the output leaves with non-temporal stores.  Chosen per launch by what reads it next: the streaming LayerNorm backward
+// (one pass, in place) runs faster behind such stores (38.2 -> 35.2 us) and the launch itself no slower; the fused first-layer
+// kernel, which reads the 134 MB right away, wants them in the caches (66 -> 76 us behind non-temporal stores).
 #ifndef MRL_ABLATE_DGRAD
 #define MRL_ABLATE_DGRAD 0   // diagnostic builds only (tools/ablate_dgrad.sh): bit 0 no output stores, 1 no split of A, 2 no MFMAs, 3 one step, 4 all blocks store to the same 128 rows
 #endif
-template <bool WPL>
+template <bool WPL, bool NT = false>
 __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
   using namespace wsplit;
   constexpr int ABL = MRL_ABLATE_DGRAD;
@@ -447,7 +460,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_split_kernel(const GemmP p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int srow = (ABL & 16) ? (row & 127) : row;   // timing-only: every block stores to the same 128 rows (cache-resident)
-        if ((ABL & 1) ? (row < p.M && acc[i][jn][r] == 1.2345e-30f) : (row < p.M)) out[(int64_t)srow * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
+        if ((ABL & 1) ? (row < p.M && acc[i][jn][r] == 1.2345e-30f) : (row < p.M)) {
+          if constexpr (NT) __builtin_nontemporal_store(acc[i][jn][r], &out[(int64_t)srow * p.ldo + n0 + wn * 64 + jn * 32 + l32]);
+          else out[(int64_t)srow * p.ldo + n0 + wn * 64 + jn * 32 + l32] = acc[i][jn][r];
+        }
       }
 }
 
