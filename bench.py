@@ -291,6 +291,7 @@ def main():
                                    'avg_launch_us': 1e3 * ms.value / n.value,
                                    'peak_basis': ('dense bf16 MFMA peak 2500 / 6 split terms per fp32 product' if split else 'dense fp32 MFMA peak'),
                                    'frac_of_fp32_mfma_peak': achieved / 157.3,
+                                   'kernel_instances': (['mrl::dgrad_split_kernel<true, false>', 'mrl::dgrad_split_kernel<true, true>'] if kname == 'mrl::dgrad_split_kernel<true>' else [kname]),
                                    'measured_over': f'a second pass of the same {args.steps} steps with HIP events around every launch of this kernel '
                                                     f'(every launch in order), {1e3 * dt_events / args.steps:.1f} ms per step'}
                 # the whole update against the same ceiling: algorithmic MACs per env step = the rollout's forward + 5 mini-epochs x
