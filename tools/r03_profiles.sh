@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence in one GPU call: bench line (both minibatch regimes), rocprofv3 kernel summaries of an update at minibatch
+# Evidence in one GPU call: bench line (both minibatch regimes), rocprofv3 kernel summaries of an update at minibatch
 # 32768 and at 2048, SAC and SHAC bench lines.  Usage: tools/r03_profiles.sh <tag>
 set -o pipefail
 TAG=${1:-r03}
